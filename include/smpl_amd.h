@@ -1,0 +1,180 @@
+/* include/smpl_amd.h -- C-ABI of the MI355X-native ARA* state-expansion engine for smpl.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, opaque handles, int status codes,
+ * nothing thrown across it.  Each entry point names the reference interface it stands behind
+ * (paths relative to the dyouakim/smpl tree).  INTEGRATION.md shows the C++ shims a maintainer
+ * adds on the smpl side (include/smpl_amd/plugin.hpp holds them ready-made).
+ *
+ * Conventions
+ *   - every function returns SMPLX_OK (0) or a negative SMPLX_E_* code; smplx_last_error() gives text
+ *   - q / state arrays hold the planning variables in planning-joint order (RobotState,
+ *     smpl/include/smpl/types.h:66)
+ *   - host pointers are copied during the call; "_device" variants take pointers into HBM and a
+ *     hipStream_t (passed as void*) and do not synchronise
+ *   - calls on one handle are serialised by the caller, like the reference's single-threaded
+ *     plugins (sbpl_collision_checking/src/collision_space.cpp:741-774 mutates state per query)
+ */
+#ifndef SMPL_AMD_H
+#define SMPL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SMPLX_OK = 0,
+    SMPLX_E_ARG = -1,        /* bad argument */
+    SMPLX_E_PARSE = -2,      /* robot / primitive text malformed */
+    SMPLX_E_LIMIT = -3,      /* exceeds a compile-time capacity */
+    SMPLX_E_HIP = -4,        /* HIP runtime error (no GPU, out of memory, ...) */
+    SMPLX_E_STATE = -5,      /* call sequence error (goal/start not set, unknown id) */
+    SMPLX_E_INVALID = -6     /* start state violates limits or is in collision */
+};
+
+typedef struct smplx_grid smplx_grid;     /* OccupancyGrid, lookup side */
+typedef struct smplx_model smplx_model;   /* RobotCollisionModel + RobotModel as flat arrays */
+typedef struct smplx_space smplx_space;   /* ManipLattice + BfsHeuristic + CollisionSpace, one query */
+
+const char* smplx_last_error(void);
+int smplx_device_count(void);
+
+/* ---- voxel grid ---------------------------------------------------------------------------
+ * sbpl::OccupancyGrid / DistanceMap, lookup side
+ * (smpl/include/smpl/occupancy_grid.h:56-304; smpl/include/smpl/distance_map/detail/distance_map.hpp:281-300,520-536).
+ * d2[nx*ny*nz]: squared cell distance to the nearest occupied or border cell, capped at
+ * ceil(max_dist/res)^2 -- the `dist` field of the reference's cells (distance_map.h:115), x-major,
+ * z fastest.  Stored in HBM as 16-bit values in 4x4x4 bricks. */
+int smplx_grid_create(const double origin[3], int nx, int ny, int nz, double res, double max_dist,
+                      const int32_t* d2, smplx_grid** out);
+void smplx_grid_destroy(smplx_grid* g);
+
+/* ---- robot model --------------------------------------------------------------------------
+ * RobotCollisionModel (sbpl_collision_checking/src/robot_collision_model.cpp:117-623),
+ * sphere trees (base_collision_models.cpp:337-444), RobotMotionCollisionModel
+ * (robot_motion_collision_model.cpp:41-275) and the planning RobotModel limits/FK
+ * (sbpl_kdl_robot_model/src/kdl_robot_model.cpp:210-235,400-423) from a plain-text description
+ * (format: DESIGN.md section 4). */
+int smplx_model_create(const char* robot_text, smplx_model** out);
+void smplx_model_destroy(smplx_model* m);
+int smplx_model_counts(const smplx_model* m, int* njoints, int* nvars, int* ntrees, int* nnodes, int* npairs, int* nslots);
+/* compiled arrays, for inspection: per joint (depth-first order) origin[12], k, file index;
+ * per node xyz+r, left, right (global indices); tree_first[ntrees+1]; pairs[2*npairs] */
+int smplx_model_joints(const smplx_model* m, double* origins, double* k, int* file_index);
+int smplx_model_nodes(const smplx_model* m, double* xyzr, int* left, int* right, int* tree_first);
+int smplx_model_pairs(const smplx_model* m, int* pairs);
+
+/* ---- planning space ------------------------------------------------------------------------ */
+typedef struct smplx_params {
+    double resolutions[16];       /* PlanningParams "discretization" (smpl_ros/src/ros/planner_interface.cpp:149-181) */
+    double bfs_inflation_radius;  /* planning_link_sphere_radius (smpl/include/smpl/planning_params.h:71) */
+    int32_t cost_per_cell;        /* planning_params.h:68 */
+    int32_t use_short_dist_mprims;
+    double short_dist_mprims_thresh;
+    int32_t use_xyzrpy_snap_mprim;    /* joint-space goals only: the action is the goal itself
+                                         (manip_lattice_action_space.cpp:551-559) */
+    double xyzrpy_snap_dist_thresh;
+    int32_t xy_rotate_by_var3;        /* [FORK] manip_lattice_action_space.cpp:590-599 */
+    int32_t use_long_and_short;
+    double padding;                   /* SelfCollisionModel m_padding, default 0 */
+    int32_t batch_states;             /* frontier batch B (0 = default 4096) */
+    int32_t reserved;
+} smplx_params;
+
+/* RobotPlanningSpace::init + insertHeuristic (smpl/include/smpl/graph/robot_planning_space.h:68,89;
+ * smpl/src/graph/manip_lattice.cpp:72-149; smpl/src/heuristic/bfs_heuristic.cpp:52-71,331-353;
+ * sbpl_collision_checking/src/collision_space.cpp:689-739).  mprim_text: .mprim file contents
+ * (manip_lattice_action_space.cpp:103-195, upstream or fork rows). */
+int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const char* mprim_text,
+                       const smplx_params* params, smplx_space** out);
+void smplx_space_destroy(smplx_space* s);
+int smplx_space_num_vars(const smplx_space* s);
+int smplx_space_num_prims(const smplx_space* s);
+int smplx_space_discretization(const smplx_space* s, int32_t* coord_vals, double* coord_deltas);
+
+/* ---- CollisionChecker (smpl/include/smpl/collision_checker.h:48-130) ---- */
+/* isStateValid (collision_space.cpp:532-536) */
+int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* valid, int32_t* lookups);
+/* isStateToStateValid (collision_space.cpp:538-581); lookups/waypoints may be NULL */
+int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, int n, uint8_t* valid,
+                              int32_t* lookups, int32_t* waypoints);
+/* interpolatePath (collision_space.cpp:583-640): waypoints of the edge a->b, out holds cap*nvars doubles */
+int smplx_cc_interpolate(smplx_space* s, const double* a, const double* b, double* out, int cap, int* n);
+/* world positions of all sphere-tree nodes for n states: out[n][nnodes][3] (RobotCollisionState::updateSphereState) */
+int smplx_cc_sphere_positions(smplx_space* s, const double* q, int n, double* out);
+
+/* ---- RobotHeuristic / BfsHeuristic (smpl/include/smpl/heuristic/robot_heuristic.h:53-101) ---- */
+/* RobotPlanningSpace::setGoal with a JOINT_STATE_GOAL (manip_lattice.cpp:2248-2287; goal pose = FK of the
+ * angles, planner_interface.cpp:1232-1235) -> BfsHeuristic::updateGoal -> BFS_3D::run to completion */
+int smplx_set_goal_joint(smplx_space* s, const double* angles, const double* tolerances);
+/* XYZ_GOAL (manip_lattice.cpp:1672-1687) */
+int smplx_set_goal_xyz(smplx_space* s, const double xyz[3], const double tol[3]);
+int smplx_goal_pose(const smplx_space* s, double xyz[3]);
+/* GetGoalHeuristic for arbitrary states (bfs_heuristic.cpp:148-163); xyz (n*3) may be NULL */
+int smplx_heuristic_batch(smplx_space* s, const double* q, int n, int32_t* h, double* xyz);
+/* the padded (nx+2)(ny+2)(nz+2) BFS_3D distance grid, node order of bfs3d.h:213-220 */
+int64_t smplx_bfs_size(const smplx_space* s);
+int smplx_bfs_copy(smplx_space* s, int32_t* out);
+int smplx_bfs_levels(const smplx_space* s);
+
+/* ---- ManipLattice (smpl/include/smpl/graph/manip_lattice.h:63-307) ---- */
+/* successor evaluation for B arbitrary parent states: the loop body of GetSuccs
+ * (manip_lattice.cpp:254-305) for every (state, primitive), dense outputs indexed [state][prim]:
+ * flags (SMPLX_F_* of device_types.h: 1 valid, 2 goal, 0x10 inactive, 0x20 limits, 0x40 collision),
+ * coord[nvars], q[nvars], h, cost, lookups.  Any output may be NULL. */
+int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q,
+                       int32_t* h, int32_t* cost, int32_t* lookups);
+/* same, everything resident in HBM; launches on `stream` and returns without synchronising.
+ * work: device scratch of smplx_expand_work_bytes(s, B) bytes.  counters (3 x uint64, may be NULL):
+ * successor evaluations, valid successors, grid lookups -- accumulated. */
+size_t smplx_expand_work_bytes(const smplx_space* s, int B);
+int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord,
+                              double* d_succ_q, int32_t* d_h, int32_t* d_cost, int32_t* d_lookups,
+                              void* d_work, uint64_t* d_counters, void* stream);
+
+/* ManipLattice::setStart (manip_lattice.cpp:1944-1981): limits + collision check, id assigned */
+int smplx_set_start(smplx_space* s, const double* q, int* id);
+int smplx_start_id(const smplx_space* s);
+int smplx_goal_id(const smplx_space* s);   /* always 0 (manip_lattice.cpp:122) */
+/* GetSuccs (manip_lattice.cpp:219-313): valid successors of a state id in primitive order */
+int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int cap, int* n);
+/* optional: ids the caller expects to expand soon (top of OPEN); they ride along in the next batch */
+int smplx_hint_frontier(smplx_space* s, const int32_t* ids, int n);
+/* RobotHeuristic::GetGoalHeuristic(state_id) */
+int smplx_get_goal_heuristic(smplx_space* s, int id, int32_t* h);
+int smplx_num_states(const smplx_space* s);
+int smplx_get_state(const smplx_space* s, int id, double* q, int32_t* coord);
+
+/* ---- the caller: ARA* (smpl/src/search/arastar.cpp:107-215,486-582) ---- */
+typedef struct smplx_search_params {
+    double initial_eps, final_eps, delta_eps;
+    int32_t improve;              /* ARAStar::setImproveSolution */
+    int32_t bounded;              /* expansion bound (TimeParameters::EXPANSIONS) */
+    int32_t max_expansions_init, max_expansions;
+} smplx_search_params;
+
+typedef struct smplx_search_stats {
+    int32_t solved;               /* 1 = success, as ARAStar::replan's return */
+    int32_t path_len, cost, expansions, expansions_init;
+    double satisfied_eps;
+    double seconds;               /* wall time inside replan */
+    int64_t gpu_succ_evals;       /* successor evaluations the GPU performed (incl. speculative) */
+    int64_t committed_succ_evals; /* evaluations belonging to committed expansions */
+    int64_t gpu_batches;
+    int64_t cache_hits, cache_misses;
+    int64_t grid_lookups;
+} smplx_search_stats;
+
+int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats);
+int smplx_expansion_log_size(const smplx_space* s);
+int smplx_expansion_log(const smplx_space* s, int32_t* out);
+/* ManipLattice::extractPath for a plain id path (manip_lattice.cpp:2018-2155): q[len][nvars] */
+int smplx_extract_path(smplx_space* s, const int32_t* ids, int len, double* q);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SMPL_AMD_H */

@@ -1,0 +1,106 @@
+// smpl_amd/csrc/device_types.h -- plain-data layout of everything the gfx950
+// kernels read: the compiled robot model (flat arrays, the form
+// sbpl_collision_checking/src/robot_collision_model.cpp:117-623 reduces a URDF to),
+// the voxel grid, the BFS grid, the motion primitives and the goal.
+#pragma once
+
+#include <stdint.h>
+
+#define SMPLX_MAX_VARS 16
+#define SMPLX_MAX_JOINTS 40
+#define SMPLX_MAX_NODES 128
+#define SMPLX_MAX_TREES 24
+#define SMPLX_MAX_PAIRS 160
+#define SMPLX_MAX_PRIMS 64
+#define SMPLX_MAX_SLOTS 2
+
+// joint transform kinds (sbpl_collision_checking/src/transform_functions.h:95-258)
+enum { SMPLX_TK_FIXED = 0, SMPLX_TK_REV_X = 1, SMPLX_TK_REV_Y = 2, SMPLX_TK_REV_Z = 3, SMPLX_TK_REV_GENERIC = 4,
+       SMPLX_TK_PRISMATIC = 5 };
+// joint types
+enum { SMPLX_JT_FIXED = 0, SMPLX_JT_REVOLUTE = 1, SMPLX_JT_CONTINUOUS = 2, SMPLX_JT_PRISMATIC = 3 };
+// where a joint's parent-link transform comes from in the depth-first joint list
+enum { SMPLX_SRC_RUNNING = -1, SMPLX_SRC_ROOT = -2 };
+// motion primitive types (smpl/include/smpl/graph/motion_primitive.h:48-67)
+enum { SMPLX_MP_LONG = -1, SMPLX_MP_SNAP_RPY = 0, SMPLX_MP_SNAP_XYZ = 1, SMPLX_MP_SNAP_XYZ_RPY = 2, SMPLX_MP_SHORT = 3 };
+// goal types (smpl/include/smpl/types.h)
+enum { SMPLX_GOAL_XYZ = 0, SMPLX_GOAL_XYZ_RPY = 1, SMPLX_GOAL_JOINT = 2 };
+// per-successor flags
+enum { SMPLX_F_VALID = 1, SMPLX_F_GOAL = 2, SMPLX_F_INACTIVE = 0x10, SMPLX_F_LIMITS = 0x20, SMPLX_F_COLLISION = 0x40 };
+
+struct SmplxJoint {          // depth-first pre-order; the child link of joint i is "link i"
+    double origin[12];       // row-major 3x4
+    double axis[3];
+    int32_t kind;            // SMPLX_TK_*
+    int32_t var;             // planning variable feeding the joint, -1 = none (fixed, or held at 0)
+    int32_t src;             // SMPLX_SRC_RUNNING / SMPLX_SRC_ROOT / >= 0: restore parent transform from that slot
+    int32_t save_slot;       // >= 0: child link transform is kept in that slot for later siblings
+    int32_t tree;            // sphere tree on the child link (index into tree_first), -1 = none
+    int32_t on_chain;        // 1 if the joint lies between the root and the planning link
+};
+
+struct SmplxNode {           // sphere-tree node; trees are stored post-order, root last
+    double c[3];
+    double r;
+    int32_t left, right;     // global node indices, -1/-1 for a leaf
+    int32_t thr;             // smallest squared cell distance that clears the sphere (bound to a grid)
+    int32_t pad;
+};
+
+struct SmplxModelDev {
+    int32_t njoints, nvars, ntrees, nnodes, npairs, nslots, nchain, pad0;
+    SmplxJoint joints[SMPLX_MAX_JOINTS];
+    SmplxNode nodes[SMPLX_MAX_NODES];
+    int32_t tree_first[SMPLX_MAX_TREES + 1];
+    int32_t tree_joint[SMPLX_MAX_TREES];      // joint whose child link carries the tree
+    int32_t pair_a[SMPLX_MAX_PAIRS], pair_b[SMPLX_MAX_PAIRS];  // tree indices, a before b in group order
+    // per planning variable
+    double var_min[SMPLX_MAX_VARS], var_max[SMPLX_MAX_VARS];   // planning limits (continuous: -pi, pi)
+    double var_min_norm[SMPLX_MAX_VARS];                        // normalize_angle(var_min)
+    double var_k[SMPLX_MAX_VARS];                               // motion-sphere factor of the owning joint
+    double coord_delta[SMPLX_MAX_VARS];
+    int32_t coord_vals[SMPLX_MAX_VARS];
+    int32_t var_type[SMPLX_MAX_VARS];                           // SMPLX_JT_*
+};
+
+struct SmplxGridDev {
+    double origin_minus_res[3];   // origin - res, as distance_map.hpp:525-527 forms it
+    double res, inv_res;
+    int32_t n[3];                 // interior cells
+    int32_t bricks[3];            // 4x4x4 bricks per axis
+    int32_t dmax_sqrd, pad;
+    const uint16_t* d2;           // brick-tiled squared cell distances
+};
+
+struct SmplxBfsDev {
+    int32_t dim_x, dim_y, dim_z, dim_xy;     // padded dims (bfs3d.cpp:61-66)
+    int32_t cost_per_cell, pad;
+    const int32_t* dist;                      // (nx+2)(ny+2)(nz+2), WALL 0x7FFFFFFF, UNDISCOVERED -1
+};
+
+struct SmplxActionsDev {
+    int32_t nprims, use_long_and_short, xy_rotate_by_var3, pad;
+    int32_t enabled[4];
+    double thresh[4];
+    int32_t type[SMPLX_MAX_PRIMS];
+    int32_t cost[SMPLX_MAX_PRIMS];            // (int)(1000 * weight)
+    double delta[SMPLX_MAX_PRIMS][SMPLX_MAX_VARS];
+};
+
+struct SmplxGoalDev {
+    int32_t type, pad;
+    double angles[SMPLX_MAX_VARS];
+    double angle_tol[SMPLX_MAX_VARS];
+    int32_t coord[SMPLX_MAX_VARS];
+    double xyz[3];
+    double xyz_tol[3];
+};
+
+// everything one query needs, resident in HBM
+struct SmplxSpaceDev {
+    SmplxModelDev model;
+    SmplxGridDev grid;
+    SmplxBfsDev bfs;
+    SmplxActionsDev actions;
+    SmplxGoalDev goal;
+};

@@ -1,0 +1,1206 @@
+// smpl_amd/csrc/engine.hip -- host side of the C-ABI (include/smpl_amd.h): handles that own HBM,
+// kernel launches, the ManipLattice state table with commit-order ids, the speculative successor
+// cache and the ARA* caller.  There is no CPU fallback: every query below runs the gfx950 kernels
+// and fails with SMPLX_E_HIP when no GPU is present.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/smpl_amd.h"
+#include "det_math.h"
+#include "device_types.h"
+#include "kernels.h"
+#include "model_compile.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int set_error(int code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return set_error(SMPLX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return SMPLX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max(n, (size_t)64);
+        HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+        cap = want;
+        return SMPLX_OK;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return SMPLX_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max(n, (size_t)64);
+        HIP_TRY(hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+        return SMPLX_OK;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+// coord -> id table: open addressing over the commit-ordered coordinate array.  State ids depend
+// only on insertion order (manip_lattice.cpp:1302-1354), never on the hash function.
+struct CoordTable {
+    int N = 0;
+    std::vector<int32_t> slots;   // id + 1, 0 = empty
+    size_t mask = 0, used = 0;
+    void init(int n)
+    {
+        N = n;
+        slots.assign(1 << 16, 0);
+        mask = slots.size() - 1;
+        used = 0;
+    }
+    static uint64_t hash(const int32_t* c, int n)
+    {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < n; ++i) {
+            h ^= (uint64_t)(uint32_t)c[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xFF51AFD7ED558CCDull;
+            h ^= h >> 33;
+        }
+        return h;
+    }
+    int find(const int32_t* c, const std::vector<int32_t>& coords) const
+    {
+        size_t i = hash(c, N) & mask;
+        while (true) {
+            const int32_t s = slots[i];
+            if (s == 0) return -1;
+            if (std::memcmp(&coords[(size_t)(s - 1) * N], c, sizeof(int32_t) * N) == 0) return s - 1;
+            i = (i + 1) & mask;
+        }
+    }
+    void insert(int id, const std::vector<int32_t>& coords)
+    {
+        if ((used + 1) * 2 > slots.size()) {
+            std::vector<int32_t> old;
+            old.swap(slots);
+            slots.assign(old.size() * 2, 0);
+            mask = slots.size() - 1;
+            for (int32_t s : old) if (s) place(s - 1, coords);
+        }
+        place(id, coords);
+        ++used;
+    }
+    void place(int id, const std::vector<int32_t>& coords)
+    {
+        size_t i = hash(&coords[(size_t)id * N], N) & mask;
+        while (slots[i]) i = (i + 1) & mask;
+        slots[i] = id + 1;
+    }
+};
+
+}  // namespace
+
+struct smplx_grid {
+    SmplxGridDev dev;
+    uint16_t* d_d2 = nullptr;
+    double origin[3];
+    double res, max_dist;
+    int n[3];
+    int dmax_int, dmax_sqrd;
+};
+
+struct smplx_model {
+    smplx::HostModel hm;
+};
+
+struct smplx_space {
+    smplx::HostModel model;
+    const smplx_grid* grid = nullptr;
+    smplx::HostActions actions;
+    smplx_params params;
+    SmplxSpaceDev hs;
+    SmplxSpaceDev* d_space = nullptr;
+    hipStream_t stream = nullptr;
+    int N = 0, M = 0;
+    size_t lds_bytes = 0;
+    // BFS
+    int32_t* d_bfs = nullptr;
+    int32_t* d_queue[2] = {nullptr, nullptr};
+    int32_t* d_counts = nullptr;
+    int64_t bfs_total = 0;
+    int bfs_levels = 0;
+    int wall_thr = -1;
+    bool goal_set = false;
+    double goal_xyz[3] = {0, 0, 0};
+    // scratch
+    DevBuf<double> b_q, b_q2, b_goal_dist, b_sq, b_xyz;
+    DevBuf<unsigned char> b_pvalid, b_flags;
+    DevBuf<int32_t> b_plook, b_coord, b_h, b_cost, b_lookups, b_way;
+    DevBuf<unsigned long long> b_counters;
+    PinBuf<double> p_q, p_sq;
+    PinBuf<unsigned char> p_flags;
+    PinBuf<int32_t> p_coord, p_h, p_lookups;
+    // lattice: commit-ordered state table (manip_lattice.cpp:1302-1354)
+    std::vector<int32_t> coords;
+    std::vector<double> qs;
+    std::vector<int32_t> h_of_id;
+    CoordTable table;
+    int start_id = -1;
+    // speculative successor cache (per state id: evaluated but not yet committed successors)
+    struct Rec { int32_t cost; int32_t h; int32_t goal; };
+    std::vector<int64_t> cache_off;     // per id: first record, -1 = not evaluated
+    std::vector<int32_t> cache_cnt;
+    std::vector<Rec> recs;
+    std::vector<int32_t> rec_coord;
+    std::vector<double> rec_q;
+    // committed successor lists (served on re-expansion in later ARA* iterations)
+    std::vector<int64_t> done_off;
+    std::vector<int32_t> done_cnt;
+    std::vector<int32_t> done_succ, done_cost;
+    std::vector<int32_t> hint;
+    // stats
+    int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0;
+    std::vector<int32_t> eval_count;    // per id: evaluated (active) primitives, for committed_evals
+    std::vector<int32_t> expansion_log;
+};
+
+namespace {
+
+int upload_space(smplx_space* s)
+{
+    HIP_TRY(hipMemcpyAsync(s->d_space, &s->hs, sizeof(SmplxSpaceDev), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+inline int blocks_for(long long n, int block) { return (int)((n + block - 1) / block); }
+
+// host mirror of ManipLattice::stateToCoord (manip_lattice.cpp:1263-1289) on det_math
+void state_to_coord(const SmplxModelDev& m, const double* q, int32_t* c)
+{
+    for (int v = 0; v < m.nvars; ++v) {
+        const double delta = m.coord_delta[v];
+        if (m.var_type[v] == SMPLX_JT_CONTINUOUS) {
+            const double pos = smplx_normalize_angle_positive(q[v]);
+            int k = (int)((pos + delta * 0.5) / delta);
+            if (k == m.coord_vals[v]) k = 0;
+            c[v] = k;
+        } else {
+            c[v] = (int)(((q[v] - m.var_min[v]) / delta) + 0.5);
+        }
+    }
+}
+
+// KDLRobotModel::checkJointLimits (kdl_robot_model.cpp:173-189, 210-235)
+bool host_check_limits(const SmplxModelDev& m, const double* q)
+{
+    for (int v = 0; v < m.nvars; ++v) {
+        double a = q[v];
+        if (std::fabs(a) > SMPLX_2PI) a = std::fmod(a, SMPLX_2PI);
+        while (a > m.var_min_norm[v]) a -= SMPLX_2PI;
+        while (a < m.var_min[v]) a += SMPLX_2PI;
+        if (a < m.var_min[v] || a > m.var_max[v]) return false;
+    }
+    return true;
+}
+
+int run_heuristic(smplx_space* s, const double* q, int n, int32_t* h, double* xyz)
+{
+    const int N = s->N;
+    if (int e = s->b_q.reserve((size_t)n * N)) return e;
+    if (int e = s->b_h.reserve(n)) return e;
+    if (int e = s->b_xyz.reserve((size_t)n * 3)) return e;
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * N, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_heuristic, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), 0, s->stream, s->d_space, s->b_q.p, n,
+                       s->b_h.p, s->b_xyz.p);
+    HIP_TRY(hipGetLastError());
+    if (h) HIP_TRY(hipMemcpyAsync(h, s->b_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
+    if (xyz) HIP_TRY(hipMemcpyAsync(xyz, s->b_xyz.p, sizeof(double) * n * 3, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+// BFS_3D::run to completion on the device (bfs3d.cpp:156-201, 507-547)
+int run_bfs(smplx_space* s, const double xyz[3])
+{
+    const smplx_grid* g = s->grid;
+    int c[3];
+    for (int a = 0; a < 3; ++a) c[a] = (int)(g->dev.inv_res * (xyz[a] - g->dev.origin_minus_res[a]) + 0.5) - 1;
+    const int dx = g->n[0] + 2, dy = g->n[1] + 2;
+    hipLaunchKernelGGL(k_bfs_reset, dim3(2048), dim3(256), 0, s->stream, s->d_bfs, (size_t)s->bfs_total);
+    HIP_TRY(hipGetLastError());
+    s->bfs_levels = 0;
+    const bool in_bounds = !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->n[0] || c[1] >= g->n[1] || c[2] >= g->n[2]);
+    if (!in_bounds) {   // bfs3d.cpp:169-171: nothing is labelled
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return SMPLX_OK;
+    }
+    const int origin = (c[2] + 1) * dx * dy + (c[1] + 1) * dx + (c[0] + 1);
+    hipLaunchKernelGGL(k_bfs_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, origin, s->d_queue[0], s->d_counts);
+    HIP_TRY(hipGetLastError());
+    int level = 0;
+    int32_t counts[3];
+    const int chunk = 32;
+    while (true) {
+        for (int k = 0; k < chunk; ++k, ++level) {
+            hipLaunchKernelGGL(k_bfs_level, dim3(1024), dim3(256), 0, s->stream, s->d_bfs, s->d_queue[level & 1],
+                               s->d_queue[(level + 1) & 1], s->d_counts, level, dx, dx * dy);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(counts, s->d_counts, sizeof(counts), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        // frontier that the next launch would consume
+        if (counts[level % 3] == 0) break;
+        if (level > s->bfs_total) return set_error(SMPLX_E_HIP, "BFS did not terminate");
+    }
+    s->bfs_levels = level;
+    return SMPLX_OK;
+}
+
+int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
+                  int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, double* d_goal_dist, unsigned char* d_pvalid,
+                  int32_t* d_plook, unsigned long long* d_counters, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_state_prep, dim3(blocks_for(B, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space,
+                       d_q, (const int64_t*)nullptr, B, d_goal_dist, d_pvalid, d_plook);
+    hipLaunchKernelGGL(k_expand, dim3(blocks_for((long long)B * s->M, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, stream,
+                       s->d_space, d_q, (const int64_t*)nullptr, B, d_goal_dist, d_pvalid, d_plook, d_flags, d_coord, d_sq,
+                       d_h, d_cost, d_lookups, d_counters);
+    HIP_TRY(hipGetLastError());
+    return SMPLX_OK;
+}
+
+int reserve_expand(smplx_space* s, int B)
+{
+    const size_t BM = (size_t)B * s->M;
+    int e;
+    if ((e = s->b_q.reserve((size_t)B * s->N))) return e;
+    if ((e = s->b_goal_dist.reserve(B))) return e;
+    if ((e = s->b_pvalid.reserve(B))) return e;
+    if ((e = s->b_plook.reserve(B))) return e;
+    if ((e = s->b_flags.reserve(BM))) return e;
+    if ((e = s->b_coord.reserve(BM * s->N))) return e;
+    if ((e = s->b_sq.reserve(BM * s->N))) return e;
+    if ((e = s->b_h.reserve(BM))) return e;
+    if ((e = s->b_cost.reserve(BM))) return e;
+    if ((e = s->b_lookups.reserve(BM))) return e;
+    if ((e = s->b_counters.reserve(4))) return e;
+    return SMPLX_OK;
+}
+
+int new_state(smplx_space* s, const int32_t* coord, const double* q, int32_t h)
+{
+    const int id = (int)(s->coords.size() / s->N);
+    s->coords.insert(s->coords.end(), coord, coord + s->N);
+    s->qs.insert(s->qs.end(), q, q + s->N);
+    s->h_of_id.push_back(h);
+    s->cache_off.push_back(-1);
+    s->cache_cnt.push_back(0);
+    s->done_off.push_back(-1);
+    s->done_cnt.push_back(0);
+    s->eval_count.push_back(0);
+    s->table.insert(id, s->coords);
+    return id;
+}
+
+void reset_lattice(smplx_space* s)
+{
+    s->coords.clear(); s->qs.clear(); s->h_of_id.clear();
+    s->cache_off.clear(); s->cache_cnt.clear(); s->recs.clear(); s->rec_coord.clear(); s->rec_q.clear();
+    s->done_off.clear(); s->done_cnt.clear(); s->done_succ.clear(); s->done_cost.clear();
+    s->eval_count.clear();
+    s->hint.clear();
+    s->table.init(s->N);
+    s->start_id = -1;
+    // id 0 is reserved for the goal (manip_lattice.cpp:122); it has no coordinate and is never hashed
+    s->coords.assign(s->N, 0);
+    s->qs.assign(s->N, 0.0);
+    s->h_of_id.push_back(0);
+    s->cache_off.push_back(-1); s->cache_cnt.push_back(0);
+    s->done_off.push_back(-1); s->done_cnt.push_back(0);
+    s->eval_count.push_back(0);
+}
+
+// evaluate the successors of `id` plus hinted frontier states in one frontier batch
+int run_batch(smplx_space* s, int id)
+{
+    const int N = s->N, M = s->M;
+    const int cap = s->params.batch_states > 0 ? s->params.batch_states : 4096;
+    std::vector<int32_t> batch;
+    batch.push_back(id);
+    s->cache_off[id] = -2;   // mark as "in this batch"
+    for (int32_t hId : s->hint) {
+        if ((int)batch.size() >= cap) break;
+        if (hId <= 0 || hId >= (int)s->cache_off.size()) continue;
+        if (s->cache_off[hId] != -1 || s->done_off[hId] >= 0) continue;
+        s->cache_off[hId] = -2;
+        batch.push_back(hId);
+    }
+    s->hint.clear();
+    const int B = (int)batch.size();
+    const size_t BM = (size_t)B * M;
+    if (int e = reserve_expand(s, B)) return e;
+    int e;
+    if ((e = s->p_q.reserve((size_t)B * N))) return e;
+    if ((e = s->p_flags.reserve(BM))) return e;
+    if ((e = s->p_coord.reserve(BM * N))) return e;
+    if ((e = s->p_sq.reserve(BM * N))) return e;
+    if ((e = s->p_h.reserve(BM))) return e;
+    for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * B * N, hipMemcpyHostToDevice, s->stream));
+    if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
+                           s->b_goal_dist.p, s->b_pvalid.p, s->b_plook.p, s->b_counters.p, s->stream))) return e;
+    HIP_TRY(hipMemcpyAsync(s->p_flags.p, s->b_flags.p, BM, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->p_h.p, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->p_coord.p, s->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->p_sq.p, s->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    ++s->gpu_batches;
+    for (int i = 0; i < B; ++i) {
+        const int sid = batch[i];
+        s->cache_off[sid] = (int64_t)s->recs.size();
+        int cnt = 0, evals = 0;
+        for (int p = 0; p < M; ++p) {
+            const size_t k = (size_t)i * M + p;
+            const unsigned char f = s->p_flags.p[k];
+            if (!(f & SMPLX_F_INACTIVE)) ++evals;
+            if (!(f & SMPLX_F_VALID)) continue;
+            smplx_space::Rec r;
+            r.cost = s->actions.dev.cost[p];
+            r.h = s->p_h.p[k];
+            r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
+            s->recs.push_back(r);
+            s->rec_coord.insert(s->rec_coord.end(), &s->p_coord.p[k * N], &s->p_coord.p[k * N] + N);
+            s->rec_q.insert(s->rec_q.end(), &s->p_sq.p[k * N], &s->p_sq.p[k * N] + N);
+            ++cnt;
+        }
+        s->cache_cnt[sid] = cnt;
+        s->eval_count[sid] = evals;
+    }
+    return SMPLX_OK;
+}
+
+// GetSuccs (manip_lattice.cpp:219-313): ids are assigned here, in the caller's sequential order
+int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** costs, int* n)
+{
+    if (id == 0) { *n = 0; *succs = nullptr; *costs = nullptr; return SMPLX_OK; }   // goal is absorbing (:231)
+    if (id < 0 || id >= (int)s->cache_off.size()) return set_error(SMPLX_E_STATE, "unknown state id");
+    if (s->done_off[id] < 0) {
+        if (s->cache_off[id] < 0) {
+            ++s->cache_misses;
+            if (int e = run_batch(s, id)) return e;
+        } else {
+            ++s->cache_hits;
+        }
+        const int64_t off = s->cache_off[id];
+        const int cnt = s->cache_cnt[id];
+        const int64_t dof = (int64_t)s->done_succ.size();
+        for (int k = 0; k < cnt; ++k) {
+            const smplx_space::Rec r = s->recs[off + k];
+            const int32_t* c = &s->rec_coord[(size_t)(off + k) * s->N];
+            int sid = s->table.find(c, s->coords);
+            if (sid < 0) sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
+            s->done_succ.push_back(r.goal ? 0 : sid);
+            s->done_cost.push_back(r.cost);
+        }
+        s->done_off[id] = dof;
+        s->done_cnt[id] = cnt;
+        s->committed_evals += s->eval_count[id];
+    }
+    *n = s->done_cnt[id];
+    *succs = s->done_succ.data() + s->done_off[id];
+    *costs = s->done_cost.data() + s->done_off[id];
+    return SMPLX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+
+extern "C" {
+
+const char* smplx_last_error(void) { return g_error.c_str(); }
+
+int smplx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int smplx_grid_create(const double origin[3], int nx, int ny, int nz, double res, double max_dist, const int32_t* d2,
+                      smplx_grid** out)
+{
+    if (!origin || !d2 || !out || nx <= 0 || ny <= 0 || nz <= 0 || !(res > 0.0)) return set_error(SMPLX_E_ARG, "bad grid arguments");
+    smplx_grid* g = new smplx_grid;
+    const double inv_res = 1.0 / res;
+    g->dmax_int = (int)std::ceil(max_dist * inv_res);   // distance_map.hpp:126
+    g->dmax_sqrd = g->dmax_int * g->dmax_int;
+    if (g->dmax_sqrd > 65535) { delete g; return set_error(SMPLX_E_LIMIT, "max_dist/res exceeds 255 cells (16-bit squared distances)"); }
+    g->res = res; g->max_dist = max_dist;
+    g->n[0] = nx; g->n[1] = ny; g->n[2] = nz;
+    const int bx = (nx + 3) / 4, by = (ny + 3) / 4, bz = (nz + 3) / 4;
+    std::vector<uint16_t> tiled((size_t)bx * by * bz * 64, 0);
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) {
+                const int v = d2[((size_t)x * ny + y) * nz + z];
+                if (v < 0 || v > g->dmax_sqrd) { delete g; return set_error(SMPLX_E_ARG, "squared distance outside [0, dmax^2]"); }
+                const size_t brick = ((size_t)(x >> 2) * by + (y >> 2)) * bz + (z >> 2);
+                tiled[brick * 64 + ((x & 3) << 4) + ((y & 3) << 2) + (z & 3)] = (uint16_t)v;
+            }
+    hipError_t e = hipMalloc((void**)&g->d_d2, tiled.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(g->d_d2, tiled.data(), tiled.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete g; return set_error(SMPLX_E_HIP, std::string("grid upload: ") + hipGetErrorString(e)); }
+    for (int a = 0; a < 3; ++a) { g->origin[a] = origin[a]; g->dev.origin_minus_res[a] = origin[a] - res; g->dev.n[a] = g->n[a]; }
+    g->dev.res = res; g->dev.inv_res = inv_res;
+    g->dev.bricks[0] = bx; g->dev.bricks[1] = by; g->dev.bricks[2] = bz;
+    g->dev.dmax_sqrd = g->dmax_sqrd; g->dev.pad = 0;
+    g->dev.d2 = g->d_d2;
+    *out = g;
+    return SMPLX_OK;
+}
+
+void smplx_grid_destroy(smplx_grid* g)
+{
+    if (!g) return;
+    if (g->d_d2) (void)hipFree(g->d_d2);
+    delete g;
+}
+
+int smplx_model_create(const char* robot_text, smplx_model** out)
+{
+    if (!robot_text || !out) return set_error(SMPLX_E_ARG, "null argument");
+    smplx_model* m = new smplx_model;
+    if (!smplx::compile_robot_text(robot_text, m->hm)) {
+        const std::string err = m->hm.error;
+        delete m;
+        return set_error(err.find("too many") != std::string::npos ? SMPLX_E_LIMIT : SMPLX_E_PARSE, err);
+    }
+    *out = m;
+    return SMPLX_OK;
+}
+
+void smplx_model_destroy(smplx_model* m) { delete m; }
+
+int smplx_model_counts(const smplx_model* m, int* njoints, int* nvars, int* ntrees, int* nnodes, int* npairs, int* nslots)
+{
+    if (!m) return set_error(SMPLX_E_ARG, "null model");
+    const SmplxModelDev& d = m->hm.dev;
+    if (njoints) *njoints = d.njoints;
+    if (nvars) *nvars = d.nvars;
+    if (ntrees) *ntrees = d.ntrees;
+    if (nnodes) *nnodes = d.nnodes;
+    if (npairs) *npairs = d.npairs;
+    if (nslots) *nslots = d.nslots;
+    return SMPLX_OK;
+}
+
+int smplx_model_joints(const smplx_model* m, double* origins, double* k, int* file_index)
+{
+    if (!m) return set_error(SMPLX_E_ARG, "null model");
+    const SmplxModelDev& d = m->hm.dev;
+    for (int j = 0; j < d.njoints; ++j) {
+        if (origins) std::memcpy(origins + 12 * (size_t)j, d.joints[j].origin, sizeof(double) * 12);
+        if (k) k[j] = m->hm.joint_k[j];
+        if (file_index) file_index[j] = m->hm.file_joint_index[j];
+    }
+    return SMPLX_OK;
+}
+
+int smplx_model_nodes(const smplx_model* m, double* xyzr, int* left, int* right, int* tree_first)
+{
+    if (!m) return set_error(SMPLX_E_ARG, "null model");
+    const SmplxModelDev& d = m->hm.dev;
+    for (int i = 0; i < d.nnodes; ++i) {
+        if (xyzr) { xyzr[4 * i] = d.nodes[i].c[0]; xyzr[4 * i + 1] = d.nodes[i].c[1]; xyzr[4 * i + 2] = d.nodes[i].c[2]; xyzr[4 * i + 3] = d.nodes[i].r; }
+        if (left) left[i] = d.nodes[i].left;
+        if (right) right[i] = d.nodes[i].right;
+    }
+    if (tree_first) for (int t = 0; t <= d.ntrees; ++t) tree_first[t] = d.tree_first[t];
+    return SMPLX_OK;
+}
+
+int smplx_model_pairs(const smplx_model* m, int* pairs)
+{
+    if (!m || !pairs) return set_error(SMPLX_E_ARG, "null argument");
+    const SmplxModelDev& d = m->hm.dev;
+    for (int i = 0; i < d.npairs; ++i) { pairs[2 * i] = d.pair_a[i]; pairs[2 * i + 1] = d.pair_b[i]; }
+    return SMPLX_OK;
+}
+
+int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const char* mprim_text, const smplx_params* params,
+                       smplx_space** out)
+{
+    if (!model || !grid || !mprim_text || !params || !out) return set_error(SMPLX_E_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(SMPLX_E_HIP, "no HIP device: the engine has no CPU path");
+    smplx_space* s = new smplx_space;
+    s->model = model->hm;
+    s->grid = grid;
+    s->params = *params;
+    s->N = s->model.dev.nvars;
+    if (!smplx::load_mprim_text(mprim_text, params->resolutions, s->N, s->actions)) {
+        const std::string err = s->actions.error;
+        delete s;
+        return set_error(SMPLX_E_PARSE, "mprim: " + err);
+    }
+    s->M = s->actions.dev.nprims;
+    SmplxActionsDev& A = s->actions.dev;
+    A.use_long_and_short = params->use_long_and_short;
+    A.xy_rotate_by_var3 = params->xy_rotate_by_var3;
+    // defaults of ManipLatticeActionSpace::init (manip_lattice_action_space.cpp:75-84), then the caller's overrides
+    for (int i = 0; i < 4; ++i) { A.enabled[i] = 0; A.thresh[i] = 0.4; }
+    A.enabled[SMPLX_MP_SHORT] = params->use_short_dist_mprims;
+    A.thresh[SMPLX_MP_SHORT] = params->short_dist_mprims_thresh;
+    A.enabled[SMPLX_MP_SNAP_XYZ_RPY] = params->use_xyzrpy_snap_mprim;
+    A.thresh[SMPLX_MP_SNAP_XYZ_RPY] = params->xyzrpy_snap_dist_thresh;
+    smplx::fill_discretization(s->model.dev, params->resolutions);
+    for (int i = 0; i < s->model.dev.nnodes; ++i)
+        s->model.dev.nodes[i].thr = smplx::sphere_threshold(s->model.dev.nodes[i].r, params->padding, grid->res, grid->dmax_sqrd);
+    s->wall_thr = smplx::wall_threshold(params->bfs_inflation_radius, grid->res, grid->dmax_sqrd);
+    s->lds_bytes = smplx_lds_bytes(s->model.dev.nnodes, s->model.dev.ntrees, s->model.dev.nslots);
+    if (s->lds_bytes > 160 * 1024) { delete s; return set_error(SMPLX_E_LIMIT, "model needs more LDS than a CU has"); }
+
+    std::memset(&s->hs, 0, sizeof(s->hs));
+    s->hs.model = s->model.dev;
+    s->hs.grid = grid->dev;
+    s->hs.actions = A;
+    s->hs.goal.type = SMPLX_GOAL_JOINT;
+
+    auto bail = [&](hipError_t e, const char* what) {
+        const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        smplx_space_destroy(s);
+        return set_error(SMPLX_E_HIP, msg);
+    };
+    hipError_t e;
+    if ((e = hipStreamCreate(&s->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
+    const int dx = grid->n[0] + 2, dy = grid->n[1] + 2, dz = grid->n[2] + 2;
+    s->bfs_total = (int64_t)dx * dy * dz;
+    const size_t qn = (size_t)grid->n[0] * grid->n[1] * grid->n[2] + 64;
+    if ((e = hipMalloc((void**)&s->d_bfs, sizeof(int32_t) * s->bfs_total)) != hipSuccess) return bail(e, "hipMalloc bfs");
+    if ((e = hipMalloc((void**)&s->d_queue[0], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
+    if ((e = hipMalloc((void**)&s->d_queue[1], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
+    if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * 4)) != hipSuccess) return bail(e, "hipMalloc bfs counts");
+    s->hs.bfs.dim_x = dx; s->hs.bfs.dim_y = dy; s->hs.bfs.dim_z = dz; s->hs.bfs.dim_xy = dx * dy;
+    s->hs.bfs.cost_per_cell = params->cost_per_cell;
+    s->hs.bfs.dist = s->d_bfs;
+    // BfsHeuristic::syncGridAndBfs (bfs_heuristic.cpp:331-353), once, at init
+    hipLaunchKernelGGL(k_bfs_init, dim3(2048), dim3(256), 0, s->stream, grid->dev, s->wall_thr, dx, dy, dz, s->d_bfs);
+    if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_bfs_init");
+    if (upload_space(s) != SMPLX_OK) { const std::string m = g_error; smplx_space_destroy(s); return set_error(SMPLX_E_HIP, m); }
+    reset_lattice(s);
+    *out = s;
+    return SMPLX_OK;
+}
+
+void smplx_space_destroy(smplx_space* s)
+{
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_space) (void)hipFree(s->d_space);
+    if (s->d_bfs) (void)hipFree(s->d_bfs);
+    if (s->d_queue[0]) (void)hipFree(s->d_queue[0]);
+    if (s->d_queue[1]) (void)hipFree(s->d_queue[1]);
+    if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int smplx_space_num_vars(const smplx_space* s) { return s ? s->N : 0; }
+int smplx_space_num_prims(const smplx_space* s) { return s ? s->M : 0; }
+
+int smplx_space_discretization(const smplx_space* s, int32_t* coord_vals, double* coord_deltas)
+{
+    if (!s) return set_error(SMPLX_E_ARG, "null space");
+    for (int v = 0; v < s->N; ++v) {
+        if (coord_vals) coord_vals[v] = s->model.dev.coord_vals[v];
+        if (coord_deltas) coord_deltas[v] = s->model.dev.coord_delta[v];
+    }
+    return SMPLX_OK;
+}
+
+int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* valid, int32_t* lookups)
+{
+    if (!s || !q || !valid || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (n == 0) return SMPLX_OK;
+    int e;
+    if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
+    if ((e = s->b_flags.reserve(n))) return e;
+    if ((e = s->b_lookups.reserve(n))) return e;
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
+                       s->b_q.p, n, s->b_flags.p, s->b_lookups.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));
+    if (lookups) HIP_TRY(hipMemcpyAsync(lookups, s->b_lookups.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, int n, uint8_t* valid, int32_t* lookups,
+                              int32_t* waypoints)
+{
+    if (!s || !a || !b || !valid || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (n == 0) return SMPLX_OK;
+    int e;
+    if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
+    if ((e = s->b_q2.reserve((size_t)n * s->N))) return e;
+    if ((e = s->b_flags.reserve(n))) return e;
+    if ((e = s->b_lookups.reserve(n))) return e;
+    if ((e = s->b_way.reserve(n))) return e;
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, a, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->b_q2.p, b, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_edge_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
+                       s->b_q.p, s->b_q2.p, n, s->b_flags.p, s->b_lookups.p, s->b_way.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));
+    if (lookups) HIP_TRY(hipMemcpyAsync(lookups, s->b_lookups.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
+    if (waypoints) HIP_TRY(hipMemcpyAsync(waypoints, s->b_way.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+int smplx_cc_interpolate(smplx_space* s, const double* a, const double* b, double* out, int cap, int* n)
+{
+    if (!s || !a || !b || !n) return set_error(SMPLX_E_ARG, "bad argument");
+    // waypoint count and interpolation are host arithmetic on det_math (collision_space.cpp:583-640,
+    // robot_motion_collision_model.h:297-320); no grid or sphere data is involved
+    const SmplxModelDev& M = s->model.dev;
+    double motion = 0.0;
+    for (int v = 0; v < M.nvars; ++v) {
+        if (M.var_type[v] == SMPLX_JT_CONTINUOUS) motion += M.var_k[v] * std::fabs(smplx_shortest_angle_diff(b[v], a[v]));
+        else if (M.var_type[v] == SMPLX_JT_REVOLUTE) motion += M.var_k[v] * std::fabs(b[v] - a[v]);
+        else if (M.var_type[v] == SMPLX_JT_PRISMATIC) motion += std::fabs(b[v] - a[v]);
+    }
+    int W = 0;
+    if (motion != 0.0) W = std::max(2, (int)std::ceil(motion / 0.05) + 1);
+    *n = W;
+    if (!out) return SMPLX_OK;
+    const double inv = W > 0 ? 1.0 / (double)(W - 1) : 0.0;
+    for (int w = 0; w < W && w < cap; ++w) {
+        const double alpha = (double)w * inv;
+        for (int v = 0; v < M.nvars; ++v) {
+            const double d = M.var_type[v] == SMPLX_JT_CONTINUOUS ? smplx_shortest_angle_diff(b[v], a[v]) : b[v] - a[v];
+            out[(size_t)w * M.nvars + v] = a[v] + alpha * d;
+        }
+    }
+    return SMPLX_OK;
+}
+
+int smplx_cc_sphere_positions(smplx_space* s, const double* q, int n, double* out)
+{
+    if (!s || !q || !out || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (n == 0) return SMPLX_OK;
+    int e;
+    const size_t cnt = (size_t)n * s->model.dev.nnodes * 3;
+    if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
+    if ((e = s->b_sq.reserve(cnt))) return e;
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_sphere_positions, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream,
+                       s->d_space, s->b_q.p, n, s->b_sq.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, s->b_sq.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+static int finish_goal(smplx_space* s)
+{
+    for (int a = 0; a < 3; ++a) s->hs.goal.xyz[a] = s->goal_xyz[a];
+    if (int e = upload_space(s)) return e;
+    if (int e = run_bfs(s, s->goal_xyz)) return e;
+    s->goal_set = true;
+    // a new goal starts a new query: the state table restarts (ids are per query)
+    reset_lattice(s);
+    // heuristic of the goal id = BFS cost at the goal pose's cell (manip_lattice.cpp:1176-1190)
+    const smplx_grid* g = s->grid;
+    int c[3];
+    for (int a = 0; a < 3; ++a) c[a] = (int)(g->dev.inv_res * (s->goal_xyz[a] - g->dev.origin_minus_res[a]) + 0.5) - 1;
+    const bool in_bounds = !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->n[0] || c[1] >= g->n[1] || c[2] >= g->n[2]);
+    s->h_of_id[0] = in_bounds ? 0 : 32767;   // the seeded cell has distance 0 (bfs3d.cpp:178)
+    return SMPLX_OK;
+}
+
+int smplx_set_goal_joint(smplx_space* s, const double* angles, const double* tolerances)
+{
+    if (!s || !angles || !tolerances) return set_error(SMPLX_E_ARG, "null argument");
+    SmplxGoalDev& G = s->hs.goal;
+    G.type = SMPLX_GOAL_JOINT;
+    for (int v = 0; v < s->N; ++v) { G.angles[v] = angles[v]; G.angle_tol[v] = tolerances[v]; }
+    state_to_coord(s->model.dev, angles, G.coord);
+    // goal pose = planning-link FK of the goal angles (planner_interface.cpp:1232-1235)
+    int32_t h;
+    if (int e = run_heuristic(s, angles, 1, &h, s->goal_xyz)) return e;
+    return finish_goal(s);
+}
+
+int smplx_set_goal_xyz(smplx_space* s, const double xyz[3], const double tol[3])
+{
+    if (!s || !xyz || !tol) return set_error(SMPLX_E_ARG, "null argument");
+    SmplxGoalDev& G = s->hs.goal;
+    G.type = SMPLX_GOAL_XYZ;
+    for (int a = 0; a < 3; ++a) { s->goal_xyz[a] = xyz[a]; G.xyz_tol[a] = tol[a]; }
+    return finish_goal(s);
+}
+
+int smplx_goal_pose(const smplx_space* s, double xyz[3])
+{
+    if (!s || !xyz) return set_error(SMPLX_E_ARG, "null argument");
+    for (int a = 0; a < 3; ++a) xyz[a] = s->goal_xyz[a];
+    return SMPLX_OK;
+}
+
+int smplx_heuristic_batch(smplx_space* s, const double* q, int n, int32_t* h, double* xyz)
+{
+    if (!s || !q || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (n == 0) return SMPLX_OK;
+    return run_heuristic(s, q, n, h, xyz);
+}
+
+int64_t smplx_bfs_size(const smplx_space* s) { return s ? s->bfs_total : 0; }
+int smplx_bfs_levels(const smplx_space* s) { return s ? s->bfs_levels : 0; }
+
+int smplx_bfs_copy(smplx_space* s, int32_t* out)
+{
+    if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(out, s->d_bfs, sizeof(int32_t) * s->bfs_total, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q, int32_t* h,
+                       int32_t* cost, int32_t* lookups)
+{
+    if (!s || !q || B < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first (the primitives are gated by goal distance)");
+    if (B == 0) return SMPLX_OK;
+    if (int e = reserve_expand(s, B)) return e;
+    const size_t BM = (size_t)B * s->M;
+    HIP_TRY(hipMemsetAsync(s->b_coord.p, 0, sizeof(int32_t) * BM * s->N, s->stream));
+    HIP_TRY(hipMemsetAsync(s->b_sq.p, 0, sizeof(double) * BM * s->N, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * B * s->N, hipMemcpyHostToDevice, s->stream));
+    if (int e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
+                              s->b_goal_dist.p, s->b_pvalid.p, s->b_plook.p, nullptr, s->stream)) return e;
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, s->b_flags.p, BM, hipMemcpyDeviceToHost, s->stream));
+    if (coord) HIP_TRY(hipMemcpyAsync(coord, s->b_coord.p, sizeof(int32_t) * BM * s->N, hipMemcpyDeviceToHost, s->stream));
+    if (succ_q) HIP_TRY(hipMemcpyAsync(succ_q, s->b_sq.p, sizeof(double) * BM * s->N, hipMemcpyDeviceToHost, s->stream));
+    if (h) HIP_TRY(hipMemcpyAsync(h, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
+    if (cost) HIP_TRY(hipMemcpyAsync(cost, s->b_cost.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
+    if (lookups) HIP_TRY(hipMemcpyAsync(lookups, s->b_lookups.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+size_t smplx_expand_work_bytes(const smplx_space* s, int B)
+{
+    (void)s;
+    // goal_dist (8) + parent_lookups (4) + parent_valid (1) per state, each 256-B aligned
+    const size_t b = (size_t)B;
+    return ((b * 8 + 255) / 256 + (b * 4 + 255) / 256 + (b + 255) / 256) * 256;
+}
+
+int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord, double* d_succ_q,
+                              int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, uint64_t* d_counters, void* stream)
+{
+    if (!s || !d_q || !d_flags || !d_coord || !d_succ_q || !d_h || !d_cost || !d_lookups || !d_work || B <= 0)
+        return set_error(SMPLX_E_ARG, "bad argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first");
+    unsigned char* w = (unsigned char*)d_work;
+    const size_t b = (size_t)B;
+    double* gd = (double*)w;
+    int32_t* pl = (int32_t*)(w + ((b * 8 + 255) / 256) * 256);
+    unsigned char* pv = w + ((b * 8 + 255) / 256 + (b * 4 + 255) / 256) * 256;
+    return launch_expand(s, d_q, B, d_flags, d_coord, d_succ_q, d_h, d_cost, d_lookups, gd, pv, pl,
+                         (unsigned long long*)d_counters, (hipStream_t)stream);
+}
+
+int smplx_set_start(smplx_space* s, const double* q, int* id)
+{
+    if (!s || !q) return set_error(SMPLX_E_ARG, "null argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "set the goal before the start (planner_interface.cpp:1469-1500 order)");
+    if (!host_check_limits(s->model.dev, q)) return set_error(SMPLX_E_INVALID, "start state violates joint limits");
+    uint8_t ok = 0;
+    if (int e = smplx_cc_state_valid_batch(s, q, 1, &ok, nullptr)) return e;
+    if (!ok) return set_error(SMPLX_E_INVALID, "start state is in collision");
+    std::vector<int32_t> c(s->N);
+    state_to_coord(s->model.dev, q, c.data());
+    int sid = s->table.find(c.data(), s->coords);
+    if (sid < 0) {
+        int32_t h = 0;
+        if (int e = run_heuristic(s, q, 1, &h, nullptr)) return e;
+        sid = new_state(s, c.data(), q, h);
+    }
+    s->start_id = sid;
+    if (id) *id = sid;
+    return SMPLX_OK;
+}
+
+int smplx_start_id(const smplx_space* s) { return s ? s->start_id : -1; }
+int smplx_goal_id(const smplx_space* s) { (void)s; return 0; }
+
+int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int cap, int* n)
+{
+    if (!s || !n) return set_error(SMPLX_E_ARG, "null argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+    const int32_t *ps, *pc;
+    int cnt = 0;
+    if (int e = get_succs(s, id, &ps, &pc, &cnt)) return e;
+    *n = cnt;
+    for (int i = 0; i < cnt && i < cap; ++i) {
+        if (succs) succs[i] = ps[i];
+        if (costs) costs[i] = pc[i];
+    }
+    return SMPLX_OK;
+}
+
+int smplx_hint_frontier(smplx_space* s, const int32_t* ids, int n)
+{
+    if (!s || (!ids && n > 0)) return set_error(SMPLX_E_ARG, "null argument");
+    s->hint.assign(ids, ids + n);
+    return SMPLX_OK;
+}
+
+int smplx_get_goal_heuristic(smplx_space* s, int id, int32_t* h)
+{
+    if (!s || !h) return set_error(SMPLX_E_ARG, "null argument");
+    if (id < 0 || id >= (int)s->h_of_id.size()) return set_error(SMPLX_E_STATE, "unknown state id");
+    *h = s->h_of_id[id];
+    return SMPLX_OK;
+}
+
+int smplx_num_states(const smplx_space* s) { return s ? (int)s->h_of_id.size() : 0; }
+
+int smplx_get_state(const smplx_space* s, int id, double* q, int32_t* coord)
+{
+    if (!s) return set_error(SMPLX_E_ARG, "null argument");
+    if (id < 0 || id >= (int)s->h_of_id.size()) return set_error(SMPLX_E_STATE, "unknown state id");
+    if (q) std::memcpy(q, &s->qs[(size_t)id * s->N], sizeof(double) * s->N);
+    if (coord) std::memcpy(coord, &s->coords[(size_t)id * s->N], sizeof(int32_t) * s->N);
+    return SMPLX_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// ARA* -- the caller (smpl/src/search/arastar.cpp).  Sequential and bit-faithful: OPEN is the
+// intrusive binary heap of smpl/include/smpl/detail/intrusive_heap.hpp (strict '<' sift rules), keys are
+// g + (unsigned)(eps*h).  The only addition is the frontier hint before a cache miss.
+// -------------------------------------------------------------------------------------------------
+
+namespace {
+
+const unsigned int kInfiniteCost = 1000000000u;   // SBPL INFINITECOST
+
+struct SearchState {
+    unsigned int g, h, f, eg;
+    unsigned short iteration_closed, call_number;
+    int bp;
+    int heap_index;
+    bool incons;
+    bool made;
+};
+
+struct Search {
+    smplx_space* sp;
+    std::vector<SearchState> st;
+    std::vector<int> heap;      // heap[0] unused
+    std::vector<int> incons;
+    double curr_eps = 1.0, initial_eps = 1.0, final_eps = 1.0, delta_eps = 1.0;
+    bool improve = true, bounded = false;
+    int max_init = 0, max_rep = 0;
+    int iteration = 1, call_number = 0;
+    double satisfied_eps = std::numeric_limits<double>::infinity();
+    int expand_count = 0, expand_count_init = 0;
+    int start_id = -1, goal_id = 0;
+    int error = SMPLX_OK;
+
+    bool less(int a, int b) const { return st[a].f < st[b].f; }
+    bool heap_empty() const { return heap.size() == 1; }
+    void heap_clear() { for (size_t i = 1; i < heap.size(); ++i) st[heap[i]].heap_index = 0; heap.resize(1); }
+    void percolate_down(size_t pivot)   // intrusive_heap.hpp:346-377
+    {
+        if (pivot >= heap.size()) return;
+        size_t left = pivot << 1, right = (pivot << 1) + 1;
+        const int tmp = heap[pivot];
+        while (left < heap.size()) {
+            size_t c = right;
+            if (right >= heap.size() || less(heap[left], heap[right])) c = left;
+            if (less(heap[c], tmp)) {
+                heap[pivot] = heap[c];
+                st[heap[pivot]].heap_index = (int)pivot;
+                pivot = c;
+            } else break;
+            left = pivot << 1; right = (pivot << 1) + 1;
+        }
+        heap[pivot] = tmp;
+        st[tmp].heap_index = (int)pivot;
+    }
+    void percolate_up(size_t pivot)     // intrusive_heap.hpp:379-395
+    {
+        const int tmp = heap[pivot];
+        while (pivot != 1) {
+            const size_t p = pivot >> 1;
+            if (less(heap[p], tmp)) break;
+            heap[pivot] = heap[p];
+            st[heap[pivot]].heap_index = (int)pivot;
+            pivot = p;
+        }
+        heap[pivot] = tmp;
+        st[tmp].heap_index = (int)pivot;
+    }
+    void push(int e) { st[e].heap_index = (int)heap.size(); heap.push_back(e); percolate_up(heap.size() - 1); }
+    void pop()
+    {
+        st[heap[1]].heap_index = 0;
+        heap[1] = heap.back();
+        heap.pop_back();
+        percolate_down(1);
+    }
+    void make() { for (size_t i = (heap.size() - 1) >> 1; i >= 1; --i) percolate_down(i); }
+
+    SearchState& get(int id)
+    {
+        if ((int)st.size() <= id) {
+            SearchState z;
+            std::memset(&z, 0, sizeof(z));
+            st.resize(id + 1, z);
+        }
+        if (!st[id].made) { st[id].made = true; st[id].call_number = 0; st[id].heap_index = 0; }
+        return st[id];
+    }
+    void reinit(int id)   // arastar.cpp:613-627
+    {
+        SearchState& s = get(id);
+        if (s.call_number != (unsigned short)call_number) {
+            int32_t h = 0;
+            smplx_get_goal_heuristic(sp, id, &h);
+            s.g = kInfiniteCost;
+            s.h = (unsigned int)h;
+            s.f = kInfiniteCost;
+            s.eg = kInfiniteCost;
+            s.iteration_closed = 0;
+            s.call_number = (unsigned short)call_number;
+            s.bp = -1;
+            s.incons = false;
+        }
+    }
+    unsigned int key(const SearchState& s) const { return s.g + (unsigned int)(long long)(curr_eps * s.h); }   // :579-582
+    void reorder_open()
+    {
+        for (size_t i = 1; i < heap.size(); ++i) st[heap[i]].f = key(st[heap[i]]);
+        make();
+    }
+    bool timed_out(int elapsed) const
+    {
+        if (!bounded) return false;
+        if (satisfied_eps == std::numeric_limits<double>::infinity()) return elapsed >= max_init;
+        return elapsed >= max_rep;
+    }
+    void expand(int sid)   // arastar.cpp:531-568
+    {
+        const int32_t *succs, *costs;
+        int n = 0;
+        if (sp->done_off[sid] < 0 && sp->cache_off[sid] < 0 && sid != 0) {
+            // about to miss: let the top of OPEN ride along in the same frontier batch
+            const int cap = sp->params.batch_states > 0 ? sp->params.batch_states : 4096;
+            sp->hint.clear();
+            for (size_t i = 1; i < heap.size() && (int)sp->hint.size() < cap - 1; ++i) sp->hint.push_back(heap[i]);
+        }
+        error = get_succs(sp, sid, &succs, &costs, &n);
+        if (error) return;
+        // copies: get_succs of a later state may grow the committed arrays
+        std::vector<int32_t> ss(succs, succs + n), cc(costs, costs + n);
+        const unsigned int eg = st[sid].eg;
+        for (int i = 0; i < n; ++i) {
+            const int nid = ss[i];
+            reinit(nid);
+            SearchState& t = st[nid];
+            const int new_cost = (int)(eg + (unsigned int)cc[i]);
+            if ((unsigned int)new_cost < t.g) {
+                t.g = (unsigned int)new_cost;
+                t.bp = sid;
+                if (t.iteration_closed != (unsigned short)iteration) {
+                    t.f = key(t);
+                    if (t.heap_index != 0) percolate_up(t.heap_index);
+                    else push(nid);
+                } else if (!t.incons) {
+                    incons.push_back(nid);
+                }
+            }
+        }
+    }
+    int improve_path(int& elapsed)   // arastar.cpp:486-527
+    {
+        while (!heap_empty()) {
+            const int m = heap[1];
+            if (st[m].f >= st[goal_id].f || m == goal_id) return 0;
+            if (timed_out(elapsed)) return 4;
+            pop();
+            st[m].iteration_closed = (unsigned short)iteration;
+            st[m].eg = st[m].g;
+            sp->expansion_log.push_back(m);
+            expand(m);
+            if (error) return 99;
+            ++elapsed;
+        }
+        return 5;
+    }
+    int replan(std::vector<int>& solution, int& cost)   // arastar.cpp:107-215, always from scratch
+    {
+        heap.assign(1, 0);
+        incons.clear();
+        ++call_number;
+        reinit(start_id);
+        reinit(goal_id);
+        st[start_id].g = 0;
+        st[start_id].f = key(st[start_id]);
+        push(start_id);
+        iteration = 1;
+        curr_eps = initial_eps;
+        satisfied_eps = std::numeric_limits<double>::infinity();
+        // goal id "changed" on a fresh search: recompute h of existing states and reorder (:155-162)
+        for (size_t i = 0; i < st.size(); ++i) {
+            if (st[i].made) { int32_t h = 0; smplx_get_goal_heuristic(sp, (int)i, &h); st[i].h = (unsigned int)h; }
+        }
+        reorder_open();
+        int num = 0, err = 0;
+        while (satisfied_eps > final_eps) {
+            if (curr_eps == satisfied_eps) {
+                if (!improve) break;
+                ++iteration;
+                curr_eps -= delta_eps;
+                curr_eps = std::max(curr_eps, final_eps);
+                for (int s : incons) { st[s].incons = false; push(s); }
+                reorder_open();
+                incons.clear();
+            }
+            err = improve_path(num);
+            if (curr_eps == initial_eps) expand_count_init += num;
+            if (err) break;
+            satisfied_eps = curr_eps;
+        }
+        expand_count += num;
+        if (satisfied_eps == std::numeric_limits<double>::infinity()) return 0;
+        for (int s = goal_id; s >= 0; s = st[s].bp) solution.push_back(s);
+        std::reverse(solution.begin(), solution.end());
+        cost = (int)st[goal_id].g;
+        return 1;
+    }
+};
+
+}  // namespace
+
+int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats)
+{
+    if (!s || !p || !stats) return set_error(SMPLX_E_ARG, "null argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+    if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
+    Search S;
+    S.sp = s;
+    S.initial_eps = p->initial_eps;
+    S.final_eps = std::max(p->final_eps, 1.0);   // ARAStar::setTargetEpsilon (arastar.h:112-114)
+    S.delta_eps = p->delta_eps;
+    S.improve = p->improve != 0;
+    S.bounded = p->bounded != 0;
+    S.max_init = p->max_expansions_init;
+    S.max_rep = p->max_expansions;
+    S.start_id = s->start_id;
+    S.goal_id = 0;
+    s->expansion_log.clear();
+    if (int e = s->b_counters.reserve(4)) return e;
+    HIP_TRY(hipMemsetAsync(s->b_counters.p, 0, sizeof(unsigned long long) * 4, s->stream));
+    const int64_t b0 = s->gpu_batches, h0 = s->cache_hits, m0 = s->cache_misses, c0 = s->committed_evals;
+    std::vector<int> sol;
+    int cost = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int ok = S.replan(sol, cost);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (S.error) return S.error;
+    unsigned long long counters[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(counters, s->b_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
+    std::memset(stats, 0, sizeof(*stats));
+    stats->solved = ok;
+    stats->path_len = (int)sol.size();
+    stats->cost = cost;
+    stats->expansions = S.expand_count;
+    stats->expansions_init = S.expand_count_init;
+    stats->satisfied_eps = S.satisfied_eps;
+    stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+    stats->gpu_succ_evals = (int64_t)counters[0];
+    stats->grid_lookups = (int64_t)counters[2];
+    stats->committed_succ_evals = s->committed_evals - c0;
+    stats->gpu_batches = s->gpu_batches - b0;
+    stats->cache_hits = s->cache_hits - h0;
+    stats->cache_misses = s->cache_misses - m0;
+    for (int i = 0; i < (int)sol.size() && i < cap; ++i) if (path_ids) path_ids[i] = sol[i];
+    return SMPLX_OK;
+}
+
+int smplx_expansion_log_size(const smplx_space* s) { return s ? (int)s->expansion_log.size() : 0; }
+
+int smplx_expansion_log(const smplx_space* s, int32_t* out)
+{
+    if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
+    std::copy(s->expansion_log.begin(), s->expansion_log.end(), out);
+    return SMPLX_OK;
+}
+
+int smplx_extract_path(smplx_space* s, const int32_t* ids, int len, double* q)
+{
+    if (!s || !ids || !q) return set_error(SMPLX_E_ARG, "null argument");
+    // manip_lattice.cpp:2018-2155: every id maps to its stored state; a trailing goal id (0) maps to the
+    // cheapest goal-satisfying successor of its predecessor
+    for (int i = 0; i < len; ++i) {
+        int id = ids[i];
+        if (id == 0) {
+            if (i == 0) return set_error(SMPLX_E_STATE, "path cannot start at the goal id");
+            const int prev = ids[i - 1];
+            if (prev <= 0 || prev >= (int)s->cache_off.size() || s->cache_off[prev] < 0)
+                return set_error(SMPLX_E_STATE, "goal predecessor was never expanded");
+            int best = -1, best_cost = std::numeric_limits<int>::max();
+            for (int k = 0; k < s->cache_cnt[prev]; ++k) {
+                const smplx_space::Rec& r = s->recs[s->cache_off[prev] + k];
+                if (!r.goal) continue;
+                const int edge_cost = 1000;   // 3-argument cost() (manip_lattice.cpp:1388-1412)
+                if (edge_cost < best_cost) { best_cost = edge_cost; best = k; }
+            }
+            if (best < 0) return set_error(SMPLX_E_STATE, "no goal successor found during path extraction");
+            std::memcpy(q + (size_t)i * s->N, &s->rec_q[(size_t)(s->cache_off[prev] + best) * s->N], sizeof(double) * s->N);
+            continue;
+        }
+        if (id < 0 || id >= (int)s->h_of_id.size()) return set_error(SMPLX_E_STATE, "unknown state id in path");
+        std::memcpy(q + (size_t)i * s->N, &s->qs[(size_t)id * s->N], sizeof(double) * s->N);
+    }
+    return SMPLX_OK;
+}
+
+}  // extern "C"

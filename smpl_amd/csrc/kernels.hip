@@ -1,0 +1,788 @@
+// smpl_amd/csrc/kernels.hip -- gfx950 (CDNA4, wave64) kernels of the ARA* state-expansion path.
+//
+//   k_state_prep      one thread per open state: planning-link FK -> metric goal distance
+//                     (manip_lattice_action_space.cpp:385-397) and the validity of the state
+//                     itself, which is waypoint 0 of every outgoing edge (collision_space.cpp:561-577)
+//   k_expand          one thread per (open state, motion primitive): gating, primitive application,
+//                     joint limits, edge collision check, discretisation, goal test, heuristic, cost
+//                     (manip_lattice.cpp:254-305 loop body)
+//   k_edge_valid      CollisionChecker::isStateToStateValid for a batch of edges
+//   k_state_valid     CollisionChecker::isStateValid for a batch of states
+//   k_heuristic       BfsHeuristic::GetGoalHeuristic for a batch of states
+//   k_bfs_*           level-synchronous 26-connected BFS (bfs3d.cpp:507-547)
+//
+// No MFMA: the path is integer/byte gathers from the voxel grid plus a short serial FK chain in fp64.
+// The sphere trees are staged in LDS; per-thread scratch (tree-root positions, saved link transforms,
+// DFS stack) lives in LDS in structure-of-arrays form (conflict-free: lane i touches word i).
+// Compile with -ffp-contract=off (arithmetic contract, det_math.h).
+#include <hip/hip_runtime.h>
+
+#include "det_math.h"
+#include "device_types.h"
+#include "kernels.h"
+
+#define BLOCK SMPLX_BLOCK
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+
+struct ThreadLds {
+    const SmplxNode* nodes;   // shared: sphere trees
+    double* d;                // per-thread doubles, SoA: d[e * BLOCK + tid]
+    unsigned char* stk;       // per-thread byte stack, SoA
+    int root_base;            // first double of root positions (3 per tree)
+    int slot_base;            // first double of saved transforms (12 per slot)
+};
+
+__device__ __forceinline__ double& lds_d(const ThreadLds& L, int e) { return L.d[e * BLOCK + threadIdx.x]; }
+__device__ __forceinline__ unsigned char& lds_b(const ThreadLds& L, int e) { return L.stk[e * BLOCK + threadIdx.x]; }
+
+// p = T * c   (robot_collision_state.h:576); ((a*x + b*y) + c*z) + t
+__device__ __forceinline__ void xform(const double T[12], const double c[3], double p[3])
+{
+    p[0] = ((T[0] * c[0] + T[1] * c[1]) + T[2] * c[2]) + T[3];
+    p[1] = ((T[4] * c[0] + T[5] * c[1]) + T[6] * c[2]) + T[7];
+    p[2] = ((T[8] * c[0] + T[9] * c[1]) + T[10] * c[2]) + T[11];
+}
+
+// local transform of a joint: origin * R(q)   (transform_functions.h:95-258)
+__device__ __forceinline__ void joint_matrix(const SmplxJoint* __restrict__ j, double q, double J[12])
+{
+    const double* o = j->origin;
+    const int kind = j->kind;
+    if (kind == SMPLX_TK_FIXED) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) J[i] = o[i];
+        return;
+    }
+    if (kind == SMPLX_TK_PRISMATIC) {   // translates along local Z whatever the axis (:218-226)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            J[4 * i + 0] = o[4 * i + 0]; J[4 * i + 1] = o[4 * i + 1]; J[4 * i + 2] = o[4 * i + 2];
+            J[4 * i + 3] = ((o[4 * i + 0] * 0.0 + o[4 * i + 1] * 0.0) + o[4 * i + 2] * q) + o[4 * i + 3];
+        }
+        return;
+    }
+    double s, c;
+    smplx_sincos(q, &s, &c);
+    if (kind == SMPLX_TK_REV_X) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            J[4 * i + 0] = o[4 * i + 0];
+            J[4 * i + 1] = c * o[4 * i + 1] + s * o[4 * i + 2];
+            J[4 * i + 2] = c * o[4 * i + 2] - s * o[4 * i + 1];
+            J[4 * i + 3] = o[4 * i + 3];
+        }
+    } else if (kind == SMPLX_TK_REV_Y) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            J[4 * i + 0] = c * o[4 * i + 0] - s * o[4 * i + 2];
+            J[4 * i + 1] = o[4 * i + 1];
+            J[4 * i + 2] = s * o[4 * i + 0] + c * o[4 * i + 2];
+            J[4 * i + 3] = o[4 * i + 3];
+        }
+    } else if (kind == SMPLX_TK_REV_Z) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            J[4 * i + 0] = o[4 * i + 0] * c + o[4 * i + 1] * s;
+            J[4 * i + 1] = o[4 * i + 1] * c - o[4 * i + 0] * s;
+            J[4 * i + 2] = o[4 * i + 2];
+            J[4 * i + 3] = o[4 * i + 3];
+        }
+    } else {   // generic axis: o * AngleAxis(q, axis)  (Eigen toRotationMatrix restated)
+        const double ax = j->axis[0], ay = j->axis[1], az = j->axis[2];
+        const double sx = s * ax, sy = s * ay, sz = s * az;
+        const double c1 = 1.0 - c;
+        const double cx = c1 * ax, cy = c1 * ay, cz = c1 * az;
+        double R[9];
+        double tmp;
+        tmp = cx * ay; R[1] = tmp - sz; R[3] = tmp + sz;
+        tmp = cx * az; R[2] = tmp + sy; R[6] = tmp - sy;
+        tmp = cy * az; R[5] = tmp - sx; R[7] = tmp + sx;
+        R[0] = cx * ax + c; R[4] = cy * ay + c; R[8] = cz * az + c;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                J[4 * i + k] = (o[4 * i + 0] * R[k] + o[4 * i + 1] * R[3 + k]) + o[4 * i + 2] * R[6 + k];
+            J[4 * i + 3] = o[4 * i + 3];
+        }
+    }
+}
+
+// T = T * J   (robot_collision_state.h:419-421)
+__device__ __forceinline__ void mul_affine(double T[12], const double J[12])
+{
+    double R[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            R[4 * i + k] = (T[4 * i + 0] * J[k] + T[4 * i + 1] * J[4 + k]) + T[4 * i + 2] * J[8 + k];
+        R[4 * i + 3] = ((T[4 * i + 0] * J[3] + T[4 * i + 1] * J[7]) + T[4 * i + 2] * J[11]) + T[4 * i + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = R[i];
+}
+
+// voxel lookup: squared cell distance at a world point, 0 outside the grid
+// (occupancy_grid.h:234 -> distance_map.hpp:281-300, 520-536)
+__device__ __forceinline__ int grid_d2(const SmplxGridDev& g, const double p[3])
+{
+    const int x = (int)(g.inv_res * (p[0] - g.origin_minus_res[0]) + 0.5) - 1;
+    const int y = (int)(g.inv_res * (p[1] - g.origin_minus_res[1]) + 0.5) - 1;
+    const int z = (int)(g.inv_res * (p[2] - g.origin_minus_res[2]) + 0.5) - 1;
+    if (x < 0 || y < 0 || z < 0 || x >= g.n[0] || y >= g.n[1] || z >= g.n[2]) return 0;
+    const size_t brick = ((size_t)(x >> 2) * g.bricks[1] + (y >> 2)) * g.bricks[2] + (z >> 2);
+    return (int)g.d2[brick * 64 + ((x & 3) << 4) + ((y & 3) << 2) + (z & 3)];
+}
+
+// interpolated value of planning variable v on the edge start -> finish at parameter alpha
+// (robot_motion_collision_model.h:221-247 diffs, 297-320 interpolate)
+__device__ __forceinline__ double edge_diff(const SmplxModelDev* __restrict__ M, int v, double sv, double fv)
+{
+    return (M->var_type[v] == SMPLX_JT_CONTINUOUS) ? smplx_shortest_angle_diff(fv, sv) : fv - sv;
+}
+
+// sphere tree vs voxel grid for the tree on the current link (collision_operations.h:105-164).
+// Returns false at the first colliding leaf.  The root position is left in LDS for the
+// sphere-sphere pass.
+__device__ __forceinline__ bool check_tree(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                           int t, const double T[12], int& lookups)
+{
+    const int root = M->tree_first[t + 1] - 1;
+    int sp = 0;
+    int node = root;
+    while (true) {
+        const SmplxNode& nd = L.nodes[node];
+        double c[3] = {nd.c[0], nd.c[1], nd.c[2]};
+        double p[3];
+        xform(T, c, p);
+        if (node == root) {
+            lds_d(L, L.root_base + 3 * t + 0) = p[0];
+            lds_d(L, L.root_base + 3 * t + 1) = p[1];
+            lds_d(L, L.root_base + 3 * t + 2) = p[2];
+        }
+        ++lookups;
+        const int d2 = grid_d2(g, p);
+        if (d2 < nd.thr) {              // CheckSphereCollision fails (collision_operations.h:67-77)
+            if (nd.left < 0) return false;
+            const double rl = L.nodes[nd.left].r, rr = L.nodes[nd.right].r;
+            // larger child is examined first (:150-156): push the other one
+            if (rl > rr) { lds_b(L, sp++) = (unsigned char)nd.right; node = nd.left; }
+            else { lds_b(L, sp++) = (unsigned char)nd.left; node = nd.right; }
+            continue;
+        }
+        if (sp == 0) break;
+        node = lds_b(L, --sp);
+    }
+    return true;
+}
+
+// value source for the configuration being checked
+struct EdgeRef {
+    const double* __restrict__ start;    // N doubles
+    const double* __restrict__ finish;   // N doubles
+    double alpha;
+};
+
+__device__ __forceinline__ double config_var(const SmplxModelDev* __restrict__ M, const EdgeRef& e, int v)
+{
+    const double sv = e.start[v];
+    if (e.alpha == 0.0) return sv;      // start + 0*diff == start exactly
+    const double d = edge_diff(M, v, sv, e.finish[v]);
+    return sv + e.alpha * d;
+}
+
+// link transforms of two trees' links for one configuration (slow path of the sphere-sphere pass)
+__device__ __noinline__ void fk_two_links(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+                                          int ja, int jb, double Ta[12], double Tb[12])
+{
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.0;
+    const int last = ja > jb ? ja : jb;
+    for (int j = 0; j <= last; ++j) {
+        const SmplxJoint* jt = &M->joints[j];
+        const double q = jt->var >= 0 ? config_var(M, e, jt->var) : 0.0;
+        double J[12];
+        joint_matrix(jt, q, J);
+        if (jt->src == SMPLX_SRC_ROOT) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = J[i];
+        } else {
+            if (jt->src >= 0) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
+            }
+            mul_affine(T, J);
+        }
+        if (jt->save_slot >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * jt->save_slot + i) = T[i];
+        }
+        if (j == ja) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Ta[i] = T[i];
+        }
+        if (j == jb) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Tb[i] = T[i];
+        }
+    }
+}
+
+// sphere tree vs sphere tree (self_collision_model.cpp:1093-1218); false = collision
+__device__ __noinline__ bool check_pair_full(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+                                             int ta, int tb)
+{
+    double Ta[12], Tb[12];
+    fk_two_links(M, L, e, M->tree_joint[ta], M->tree_joint[tb], Ta, Tb);
+    int sp = 0;
+    int na = M->tree_first[ta + 1] - 1, nb = M->tree_first[tb + 1] - 1;
+    while (true) {
+        const SmplxNode& A = L.nodes[na];
+        const SmplxNode& B = L.nodes[nb];
+        double ca[3] = {A.c[0], A.c[1], A.c[2]}, cb[3] = {B.c[0], B.c[1], B.c[2]};
+        double pa[3], pb[3];
+        xform(Ta, ca, pa);
+        xform(Tb, cb, pb);
+        const double dx = pb[0] - pa[0], dy = pb[1] - pa[1], dz = pb[2] - pa[2];
+        const double cd2 = (dx * dx + dy * dy) + dz * dz;
+        const double rr = A.r + B.r;
+        if (!(cd2 > rr * rr)) {
+            const bool la = A.left < 0, lb = B.left < 0;
+            if (la && lb) return false;   // leaf x leaf: the ACM lookup by sphere name never matches (:1136)
+            bool split_a;
+            if (la) split_a = false;
+            else if (lb) split_a = true;
+            else split_a = A.r > B.r;
+            // both children are visited unless pruned; visiting order does not change the boolean
+            if (split_a) {
+                lds_b(L, sp++) = (unsigned char)A.right; lds_b(L, sp++) = (unsigned char)nb;
+                na = A.left;
+            } else {
+                lds_b(L, sp++) = (unsigned char)na; lds_b(L, sp++) = (unsigned char)B.right;
+                nb = B.left;
+            }
+            continue;
+        }
+        if (sp == 0) break;
+        nb = lds_b(L, --sp);
+        na = lds_b(L, --sp);
+    }
+    return true;
+}
+
+// CollisionSpace::isStateValid for one configuration (collision_space.cpp:532-536 ->
+// self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
+// link pairs sphere-vs-sphere.
+__device__ __forceinline__ bool config_valid(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                             const EdgeRef& e, int& lookups)
+{
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.0;
+    const int nj = M->njoints;
+    for (int j = 0; j < nj; ++j) {
+        const SmplxJoint* jt = &M->joints[j];
+        const double q = jt->var >= 0 ? config_var(M, e, jt->var) : 0.0;
+        double J[12];
+        joint_matrix(jt, q, J);
+        if (jt->src == SMPLX_SRC_ROOT) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = J[i];
+        } else {
+            if (jt->src >= 0) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
+            }
+            mul_affine(T, J);
+        }
+        if (jt->save_slot >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * jt->save_slot + i) = T[i];
+        }
+        if (jt->tree >= 0) {
+            if (!check_tree(M, L, g, jt->tree, T, lookups)) return false;
+        }
+    }
+    const int np = M->npairs;
+    for (int k = 0; k < np; ++k) {
+        const int ta = M->pair_a[k], tb = M->pair_b[k];
+        const SmplxNode& A = L.nodes[M->tree_first[ta + 1] - 1];
+        const SmplxNode& B = L.nodes[M->tree_first[tb + 1] - 1];
+        const double dx = lds_d(L, L.root_base + 3 * tb + 0) - lds_d(L, L.root_base + 3 * ta + 0);
+        const double dy = lds_d(L, L.root_base + 3 * tb + 1) - lds_d(L, L.root_base + 3 * ta + 1);
+        const double dz = lds_d(L, L.root_base + 3 * tb + 2) - lds_d(L, L.root_base + 3 * ta + 2);
+        const double cd2 = (dx * dx + dy * dy) + dz * dz;
+        const double rr = A.r + B.r;
+        if (cd2 > rr * rr) continue;
+        if (A.left < 0 && B.left < 0) return false;
+        if (!check_pair_full(M, L, e, ta, tb)) return false;
+    }
+    return true;
+}
+
+// CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
+// (the start configuration), whose result the caller already has.
+__device__ __forceinline__ bool edge_valid(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                           const double* __restrict__ start, const double* __restrict__ finish,
+                                           bool start_known, bool start_valid, int& lookups, int& waypoints)
+{
+    // robot_motion_collision_model.cpp:371-407, .h:352-366, 173-181
+    double motion = 0.0;
+    const int nv = M->nvars;
+    for (int v = 0; v < nv; ++v) {
+        const int ty = M->var_type[v];
+        const double sv = start[v], fv = finish[v];
+        if (ty == SMPLX_JT_CONTINUOUS) motion += M->var_k[v] * fabs(smplx_shortest_angle_diff(fv, sv));
+        else if (ty == SMPLX_JT_REVOLUTE) motion += M->var_k[v] * fabs(fv - sv);
+        else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
+    }
+    int W = 0;
+    if (motion != 0.0) {
+        W = (int)ceil(motion / 0.05) + 1;
+        if (W < 2) W = 2;
+    }
+    waypoints = W;
+    if (W == 0) return true;
+    if (start_known && !start_valid) return false;
+    const double inv = 1.0 / (double)(W - 1);
+    EdgeRef e;
+    e.start = start;
+    e.finish = finish;
+    if (W > 5) {
+        for (int i = 0; i < 5; ++i) {
+            for (int j = i; j < W; j += 5) {
+                if (j == 0 && start_known) continue;
+                e.alpha = (double)j * inv;
+                if (!config_valid(M, L, g, e, lookups)) return false;
+            }
+        }
+    } else {
+        for (int j = start_known ? 1 : 0; j < W; ++j) {
+            e.alpha = (double)j * inv;
+            if (!config_valid(M, L, g, e, lookups)) return false;
+        }
+    }
+    return true;
+}
+
+// planning-link position ("KDL" FK restated as the same serial chain; kdl_robot_model.cpp:400-423,
+// continuous joints normalised first :191-198)
+__device__ __forceinline__ void planning_fk(const SmplxModelDev* __restrict__ M, const double* __restrict__ q, double p[3])
+{
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.0;
+    bool first = true;
+    const int nj = M->njoints;
+    for (int j = 0; j < nj; ++j) {
+        const SmplxJoint* jt = &M->joints[j];
+        if (!jt->on_chain) continue;
+        double qv = 0.0;
+        if (jt->var >= 0) {
+            qv = q[jt->var];
+            if (M->var_type[jt->var] == SMPLX_JT_CONTINUOUS) qv = smplx_normalize_angle(qv);
+        }
+        double J[12];
+        joint_matrix(jt, qv, J);
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = J[i];
+            first = false;
+        } else {
+            mul_affine(T, J);
+        }
+    }
+    p[0] = T[3]; p[1] = T[7]; p[2] = T[11];
+}
+
+__device__ __forceinline__ void world_to_cell(const SmplxGridDev& g, const double p[3], int c[3])
+{
+    c[0] = (int)(g.inv_res * (p[0] - g.origin_minus_res[0]) + 0.5) - 1;
+    c[1] = (int)(g.inv_res * (p[1] - g.origin_minus_res[1]) + 0.5) - 1;
+    c[2] = (int)(g.inv_res * (p[2] - g.origin_minus_res[2]) + 0.5) - 1;
+}
+
+// BFS_3D::inBounds / getNode (bfs3d.h:151-155, 213-220)
+__device__ __forceinline__ bool bfs_in_bounds(const SmplxBfsDev& b, const int c[3])
+{
+    return !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= b.dim_x - 2 || c[1] >= b.dim_y - 2 || c[2] >= b.dim_z - 2);
+}
+__device__ __forceinline__ int bfs_dist(const SmplxBfsDev& b, const int c[3])
+{
+    return b.dist[(size_t)(c[2] + 1) * b.dim_xy + (size_t)(c[1] + 1) * b.dim_x + (c[0] + 1)];
+}
+
+// BfsHeuristic::getBfsCostToGoal (bfs_heuristic.cpp:355-366)
+__device__ __forceinline__ int bfs_cost_to_goal(const SmplxBfsDev& b, const int c[3])
+{
+    if (!bfs_in_bounds(b, c)) return 32767;
+    const int d = bfs_dist(b, c);
+    if (d == 0x7FFFFFFF) return 32767;
+    return b.cost_per_cell * d;
+}
+
+// KDLRobotModel::checkJointLimits (kdl_robot_model.cpp:173-189, 210-235)
+__device__ __forceinline__ bool check_joint_limits(const SmplxModelDev* __restrict__ M, const double* __restrict__ q)
+{
+    const int nv = M->nvars;
+    for (int v = 0; v < nv; ++v) {
+        const double a_min = M->var_min[v], a_max = M->var_min_norm[v];
+        double a = q[v];
+        if (fabs(a) > SMPLX_2PI) a = fmod(a, SMPLX_2PI);
+        while (a > a_max) a -= SMPLX_2PI;
+        while (a < a_min) a += SMPLX_2PI;
+        if (a < M->var_min[v] || a > M->var_max[v]) return false;
+    }
+    return true;
+}
+
+// ManipLattice::stateToCoord for one variable (manip_lattice.cpp:1263-1289)
+__device__ __forceinline__ int var_to_coord(const SmplxModelDev* __restrict__ M, int v, double x)
+{
+    const double delta = M->coord_delta[v];
+    const int ty = M->var_type[v];
+    if (ty == SMPLX_JT_CONTINUOUS) {
+        const double pos = smplx_normalize_angle_positive(x);
+        int c = (int)((pos + delta * 0.5) / delta);
+        if (c == M->coord_vals[v]) c = 0;
+        return c;
+    }
+    // bounded variables (every non-continuous variable of the plain-text model has limits)
+    return (int)(((x - M->var_min[v]) / delta) + 0.5);
+}
+
+__device__ __forceinline__ ThreadLds setup_lds(const SmplxModelDev* __restrict__ M, unsigned char* smem)
+{
+    ThreadLds L;
+    SmplxNode* nodes = reinterpret_cast<SmplxNode*>(smem);
+    const int nn = M->nnodes;
+    // cooperative copy of the sphere trees (48 B per node) into LDS
+    const int words = nn * (int)(sizeof(SmplxNode) / 8);
+    const double* src = reinterpret_cast<const double*>(M->nodes);
+    double* dst = reinterpret_cast<double*>(nodes);
+    for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+    L.nodes = nodes;
+    L.d = reinterpret_cast<double*>(smem + (size_t)nn * sizeof(SmplxNode));
+    L.root_base = 0;
+    L.slot_base = 3 * M->ntrees;
+    const int nd = 3 * M->ntrees + 12 * M->nslots;
+    L.stk = reinterpret_cast<unsigned char*>(L.d + (size_t)nd * BLOCK);
+    __syncthreads();
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+             double* __restrict__ goal_dist, unsigned char* __restrict__ parent_valid, int* __restrict__ parent_lookups)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = &S->model;
+    ThreadLds L = setup_lds(M, smem);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= B) return;
+    const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
+    double p[3];
+    planning_fk(M, q, p);
+    // BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138)
+    int c[3];
+    world_to_cell(S->grid, p, c);
+    double gd;
+    if (!bfs_in_bounds(S->bfs, c)) gd = (double)0x7FFFFFFF * S->grid.res;
+    else gd = (double)bfs_dist(S->bfs, c) * S->grid.res;
+    goal_dist[i] = gd;
+    EdgeRef e;
+    e.start = q; e.finish = q; e.alpha = 0.0;
+    int lk = 0;
+    const bool ok = config_valid(M, L, S->grid, e, lk);
+    parent_valid[i] = ok ? 1 : 0;
+    parent_lookups[i] = lk;
+}
+
+// manip_lattice_action_space.cpp:662-691
+__device__ __forceinline__ bool mprim_active(const SmplxActionsDev& A, double goal_dist, int type)
+{
+    if (type == SMPLX_MP_LONG) {
+        if (A.use_long_and_short) return true;
+        const bool near_goal = goal_dist <= A.thresh[SMPLX_MP_SHORT];
+        return !(A.enabled[SMPLX_MP_SHORT] && near_goal);
+    } else if (type == SMPLX_MP_SHORT) {
+        if (A.use_long_and_short) return A.enabled[type] != 0;
+        const bool near_goal = goal_dist <= A.thresh[type];
+        return A.enabled[type] && near_goal;
+    }
+    return A.enabled[type] && goal_dist <= A.thresh[type];
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+         const double* __restrict__ goal_dist, const unsigned char* __restrict__ parent_valid,
+         const int* __restrict__ parent_lookups,
+         unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
+         int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
+         unsigned long long* __restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = &S->model;
+    const SmplxActionsDev& A = S->actions;
+    ThreadLds L = setup_lds(M, smem);
+    const int nprims = A.nprims;
+    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool in_range = tid < (long long)B * nprims;
+    int flags = SMPLX_F_INACTIVE;
+    int lookups = 0;
+    int evaluated = 0;
+    if (in_range) {
+        const int si = (int)(tid / nprims);
+        const int pi = (int)(tid - (long long)si * nprims);
+        const int nv = M->nvars;
+        const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
+        double* sq = out_q + tid * nv;
+        int* sc = out_coord + tid * nv;
+        const int type = A.type[pi];
+        int h = 0, cost = 0;
+        bool have_action = false;
+        if (mprim_active(A, goal_dist[si], type)) {
+            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+                // applyMotionPrimitive (manip_lattice_action_space.cpp:575-621)
+                double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
+                if (A.xy_rotate_by_var3 && nv > 3) {
+                    double s, c;
+                    smplx_sincos(parent[3], &s, &c);
+                    const double a0 = d0, a1 = d1;
+                    d0 = c * a0 + (-s) * a1;
+                    d1 = s * a0 + c * a1;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
+                    sq[v] = d + parent[v];
+                }
+                have_action = true;
+            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && S->goal.type == SMPLX_GOAL_JOINT) {
+                for (int v = 0; v < nv; ++v) sq[v] = S->goal.angles[v];   // :551-559
+                have_action = true;
+            }
+        }
+        if (have_action) {
+            evaluated = 1;
+            flags = 0;
+            if (!check_joint_limits(M, sq)) {
+                flags = SMPLX_F_LIMITS;
+            } else {
+                int W = 0;
+                int lk = 0;
+                const bool ok = edge_valid(M, L, S->grid, parent, sq, true, parent_valid[si] != 0, lk, W);
+                lookups = lk;
+                if (W > 0) lookups += parent_lookups[si];   // waypoint 0, done once per state by k_state_prep
+                if (!ok) {
+                    flags = SMPLX_F_COLLISION;
+                } else {
+                    for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
+                    bool is_goal;
+                    double p[3];
+                    planning_fk(M, sq, p);
+                    if (S->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
+                        is_goal = true;
+                        for (int v = 0; v < nv; ++v)
+                            if (fabs((double)(sc[v] - S->goal.coord[v])) > S->goal.angle_tol[v]) is_goal = false;
+                    } else {                                      // XYZ goal :1672-1687
+                        is_goal = fabs(p[0] - S->goal.xyz[0]) <= S->goal.xyz_tol[0] &&
+                                  fabs(p[1] - S->goal.xyz[1]) <= S->goal.xyz_tol[1] &&
+                                  fabs(p[2] - S->goal.xyz[2]) <= S->goal.xyz_tol[2];
+                    }
+                    int c[3];
+                    world_to_cell(S->grid, p, c);
+                    h = bfs_cost_to_goal(S->bfs, c);
+                    cost = A.cost[pi];
+                    flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
+                }
+            }
+        }
+        out_flags[tid] = (unsigned char)flags;
+        out_h[tid] = h;
+        out_cost[tid] = cost;
+        out_lookups[tid] = lookups;
+    }
+    // per-wave tallies: ballots instead of one atomic per lane
+    if (counters) {
+        const unsigned long long m_eval = __ballot(evaluated);
+        const unsigned long long m_valid = __ballot((flags & SMPLX_F_VALID) != 0);
+        int lk = lookups;
+        for (int off = 32; off > 0; off >>= 1) lk += __shfl_down(lk, off);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters[0], (unsigned long long)__popcll(m_eval));
+            atomicAdd(&counters[1], (unsigned long long)__popcll(m_valid));
+            atomicAdd(&counters[2], (unsigned long long)lk);
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq, const double* __restrict__ Bq, int n,
+             unsigned char* __restrict__ out, int* __restrict__ out_lookups, int* __restrict__ out_waypoints)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = &S->model;
+    ThreadLds L = setup_lds(M, smem);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int lk = 0, W = 0;
+    const bool ok = edge_valid(M, L, S->grid, Aq + (size_t)i * M->nvars, Bq + (size_t)i * M->nvars, false, true, lk, W);
+    out[i] = ok ? 1 : 0;
+    if (out_lookups) out_lookups[i] = lk;
+    if (out_waypoints) out_waypoints[i] = W;
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, unsigned char* __restrict__ out,
+              int* __restrict__ out_lookups)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = &S->model;
+    ThreadLds L = setup_lds(M, smem);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    EdgeRef e;
+    e.start = Q + (size_t)i * M->nvars; e.finish = e.start; e.alpha = 0.0;
+    int lk = 0;
+    const bool ok = config_valid(M, L, S->grid, e, lk);
+    out[i] = ok ? 1 : 0;
+    if (out_lookups) out_lookups[i] = lk;
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_heuristic(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, int* __restrict__ out_h,
+            double* __restrict__ out_xyz)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const SmplxModelDev* M = &S->model;
+    double p[3];
+    planning_fk(M, Q + (size_t)i * M->nvars, p);
+    int c[3];
+    world_to_cell(S->grid, p, c);
+    out_h[i] = bfs_cost_to_goal(S->bfs, c);
+    if (out_xyz) { out_xyz[3 * i] = p[0]; out_xyz[3 * i + 1] = p[1]; out_xyz[3 * i + 2] = p[2]; }
+}
+
+// debug/parity: world positions of every tree node for one configuration per thread
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, double* __restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = &S->model;
+    ThreadLds L = setup_lds(M, smem);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double* q = Q + (size_t)i * M->nvars;
+    double T[12];
+    for (int k = 0; k < 12; ++k) T[k] = 0.0;
+    for (int j = 0; j < M->njoints; ++j) {
+        const SmplxJoint* jt = &M->joints[j];
+        double J[12];
+        joint_matrix(jt, jt->var >= 0 ? q[jt->var] : 0.0, J);
+        if (jt->src == SMPLX_SRC_ROOT) {
+            for (int k = 0; k < 12; ++k) T[k] = J[k];
+        } else {
+            if (jt->src >= 0) for (int k = 0; k < 12; ++k) T[k] = lds_d(L, L.slot_base + 12 * jt->src + k);
+            mul_affine(T, J);
+        }
+        if (jt->save_slot >= 0) for (int k = 0; k < 12; ++k) lds_d(L, L.slot_base + 12 * jt->save_slot + k) = T[k];
+        if (jt->tree >= 0) {
+            for (int nd = M->tree_first[jt->tree]; nd < M->tree_first[jt->tree + 1]; ++nd) {
+                double c[3] = {L.nodes[nd].c[0], L.nodes[nd].c[1], L.nodes[nd].c[2]};
+                double p[3];
+                xform(T, c, p);
+                double* o = out + ((size_t)i * M->nnodes + nd) * 3;
+                o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BFS-3D (bfs3d.cpp:156-201 run, 507-547 search).  Level-synchronous: one launch expands the
+// whole frontier of distance d into the frontier of distance d+1.  Labels are exact BFS hop
+// counts whatever the order inside a level, so the result equals the sequential queue's.
+// ---------------------------------------------------------------------------------------------
+
+// walls: BfsHeuristic::syncGridAndBfs (bfs_heuristic.cpp:331-353) in integer form:
+// wall iff squared cell distance <= wall_thr (largest i with res*sqrt(i) <= radius; -1 if none)
+extern "C" __global__ void __launch_bounds__(256)
+k_bfs_init(SmplxGridDev g, int wall_thr, int dim_x, int dim_y, int dim_z, int* __restrict__ dist)
+{
+    const size_t total = (size_t)dim_x * dim_y * dim_z;
+    for (size_t node = (size_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (size_t)gridDim.x * 256) {
+        const int x = (int)(node % dim_x), y = (int)(node / dim_x % dim_y), z = (int)(node / ((size_t)dim_x * dim_y));
+        int v;
+        if (x == 0 || x == dim_x - 1 || y == 0 || y == dim_y - 1 || z == 0 || z == dim_z - 1) {
+            v = 0x7FFFFFFF;
+        } else {
+            const int cx = x - 1, cy = y - 1, cz = z - 1;
+            const size_t brick = ((size_t)(cx >> 2) * g.bricks[1] + (cy >> 2)) * g.bricks[2] + (cz >> 2);
+            const int d2 = (int)g.d2[brick * 64 + ((cx & 3) << 4) + ((cy & 3) << 2) + (cz & 3)];
+            v = d2 <= wall_thr ? 0x7FFFFFFF : -1;
+        }
+        dist[node] = v;
+    }
+}
+
+// BFS_3D::run reset: every non-wall cell back to UNDISCOVERED (bfs3d.cpp:162-166)
+extern "C" __global__ void __launch_bounds__(256)
+k_bfs_reset(int* __restrict__ dist, size_t total)
+{
+    for (size_t node = (size_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (size_t)gridDim.x * 256)
+        if (dist[node] != 0x7FFFFFFF) dist[node] = -1;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_bfs_seed(int* __restrict__ dist, int origin, int* __restrict__ queue, int* __restrict__ counts)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dist[origin] = 0;      // overwrites a wall at the goal cell, as bfs3d.cpp:178 does
+        queue[0] = origin;
+        counts[0] = 1;
+        counts[1] = 0;
+        counts[2] = 0;
+    }
+}
+
+// counts[level % 3] = size of the input frontier, counts[(level + 1) % 3] = size of the output frontier;
+// counts[(level + 2) % 3] (the previous input) is cleared here for the level after next.
+extern "C" __global__ void __launch_bounds__(256)
+k_bfs_level(int* __restrict__ dist, const int* __restrict__ q_in, int* __restrict__ q_out, int* __restrict__ counts,
+            int level, int dim_x, int dim_xy)
+{
+    const int n_in = counts[level % 3];
+    int* n_out = &counts[(level + 1) % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(level + 2) % 3] = 0;
+    const int w = dim_x, p = dim_xy;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_in; i += gridDim.x * 256) {
+        const int cur = q_in[i];
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0 && dz == 0) continue;
+                    const int nb = cur + dz * p + dy * w + dx;
+                    if (dist[nb] < 0) {
+                        if (atomicCAS(&dist[nb], -1, level + 1) == -1) {
+                            const int slot = atomicAdd(n_out, 1);
+                            q_out[slot] = nb;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}

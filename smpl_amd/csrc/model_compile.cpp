@@ -1,0 +1,556 @@
+// smpl_amd/csrc/model_compile.cpp -- see model_compile.h.  Host-only C++ (built with -ffp-contract=off).
+#include "model_compile.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <sstream>
+
+#include "det_math.h"
+
+namespace smplx {
+
+namespace {
+
+struct JointRow {
+    std::string name, parent, child;
+    int type = SMPLX_JT_FIXED;
+    double xyz[3] = {0, 0, 0}, rpy[3] = {0, 0, 0}, axis[3] = {0, 0, 1};
+    double lo = 0, hi = 0;
+    int parent_link = -1, child_link = -1;
+};
+
+struct SphereRow {
+    std::string link, name;
+    double c[3] = {0, 0, 0};
+    double r = 0;
+    int priority = 1;
+};
+
+struct V3 { double x = 0, y = 0, z = 0; };
+
+double vnorm(double x, double y, double z) { return std::sqrt((x * x + y * y) + z * z); }
+
+// rotation matrix of an angle-axis pair (Eigen AngleAxisd::toRotationMatrix restated;
+// used by robot_motion_collision_model.cpp:170-173)
+void angle_axis(double angle, const double ax[3], double R[9])
+{
+    double s, c;
+    smplx_sincos(angle, &s, &c);
+    const double sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
+    const double c1 = 1.0 - c;
+    const double cx = c1 * ax[0], cy = c1 * ax[1], cz = c1 * ax[2];
+    double tmp;
+    tmp = cx * ax[1]; R[1] = tmp - sz; R[3] = tmp + sz;
+    tmp = cx * ax[2]; R[2] = tmp + sy; R[6] = tmp - sy;
+    tmp = cy * ax[2]; R[5] = tmp - sx; R[7] = tmp + sx;
+    R[0] = cx * ax[0] + c; R[4] = cy * ax[1] + c; R[8] = cz * ax[2] + c;
+}
+
+// urdf origin: Translation(xyz) * Rz(yaw) * Ry(pitch) * Rx(roll)
+void origin_matrix(const double xyz[3], const double rpy[3], double o[12])
+{
+    double sr, cr, sp, cp, sy, cy;
+    smplx_sincos(rpy[0], &sr, &cr);
+    smplx_sincos(rpy[1], &sp, &cp);
+    smplx_sincos(rpy[2], &sy, &cy);
+    o[0] = cy * cp; o[1] = (cy * sp) * sr - sy * cr; o[2] = (cy * sp) * cr + sy * sr; o[3] = xyz[0];
+    o[4] = sy * cp; o[5] = (sy * sp) * sr + cy * cr; o[6] = (sy * sp) * cr - cy * sr; o[7] = xyz[1];
+    o[8] = -sp;     o[9] = cp * sr;                  o[10] = cp * cr;                 o[11] = xyz[2];
+}
+
+V3 apply12(const double T[12], V3 c)
+{
+    V3 p;
+    p.x = ((T[0] * c.x + T[1] * c.y) + T[2] * c.z) + T[3];
+    p.y = ((T[4] * c.x + T[5] * c.y) + T[6] * c.z) + T[7];
+    p.z = ((T[8] * c.x + T[9] * c.y) + T[10] * c.z) + T[11];
+    return p;
+}
+
+// ---- bounding sphere tree of one link (base_collision_models.cpp:337-444, 569-641) ----
+struct TreeBuilder {
+    const std::vector<SphereRow>& leaves;   // spheres of the link, config order
+    std::vector<SmplxNode> out;             // post-order, tree-local child indices
+    std::vector<int> perm;
+
+    explicit TreeBuilder(const std::vector<SphereRow>& l) : leaves(l)
+    {
+        for (size_t i = 0; i < l.size(); ++i) perm.push_back((int)i);
+    }
+
+    int axis_of_largest_extent(int lo, int hi) const
+    {
+        double mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) mn[a] = mx[a] = leaves[perm[lo]].c[a];
+        for (int i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const double v = leaves[perm[i]].c[a];
+                if (v < mn[a]) mn[a] = v;
+                if (v > mx[a]) mx[a] = v;
+            }
+        const double sx = mx[0] - mn[0], sy = mx[1] - mn[1], sz = mx[2] - mn[2];
+        if (sx > sy && sx > sz) return 0;
+        if (sy > sz) return 1;
+        return 2;
+    }
+
+    // GNU std::partition for bidirectional iterators, on perm[lo, hi): the reference's
+    // std::partition (base_collision_models.cpp:394-400) leaves an implementation-defined order
+    int split(int lo, int hi, int axis, double pivot)
+    {
+        int first = lo, last = hi;
+        auto pred = [&](int idx) { return leaves[idx].c[axis] < pivot; };
+        while (true) {
+            while (true) {
+                if (first == last) return first;
+                if (pred(perm[first])) ++first; else break;
+            }
+            --last;
+            while (true) {
+                if (first == last) return first;
+                if (!pred(perm[last])) --last; else break;
+            }
+            std::swap(perm[first], perm[last]);
+            ++first;
+        }
+    }
+
+    int build(int lo, int hi)
+    {
+        const int count = hi - lo;
+        if (count == 1) {
+            const SphereRow& s = leaves[perm[lo]];
+            SmplxNode n;
+            std::memset(&n, 0, sizeof(n));
+            n.c[0] = s.c[0]; n.c[1] = s.c[1]; n.c[2] = s.c[2];
+            n.r = s.r;
+            n.left = n.right = -1;
+            out.push_back(n);
+            return (int)out.size() - 1;
+        }
+        const int axis = axis_of_largest_extent(lo, hi);
+        double cc[3] = {0.0, 0.0, 0.0};
+        for (int i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) cc[a] = cc[a] + leaves[perm[i]].c[a];
+        for (int a = 0; a < 3; ++a) cc[a] = cc[a] / (double)count;
+        double cr = 0.0;
+        for (int i = lo; i < hi; ++i) {
+            const SphereRow& s = leaves[perm[i]];
+            const double rad = vnorm(s.c[0] - cc[0], s.c[1] - cc[1], s.c[2] - cc[2]) + s.r;
+            if (rad > cr) cr = rad;
+        }
+        int mid = split(lo, hi, axis, cc[axis]);
+        if (mid == lo || mid == hi) mid = lo + (count >> 1);
+        const int li = build(lo, mid);
+        const int ri = build(mid, hi);
+        // computeOptimalBoundingSphere (:569-592)
+        const SmplxNode& s1 = out[li];
+        const SmplxNode& s2 = out[ri];
+        const double vx = s2.c[0] - s1.c[0], vy = s2.c[1] - s1.c[1], vz = s2.c[2] - s1.c[2];
+        const double dist = vnorm(vx, vy, vz);
+        double gc[3], gr;
+        if (s1.r > dist + s2.r) {
+            gc[0] = s1.c[0]; gc[1] = s1.c[1]; gc[2] = s1.c[2]; gr = s1.r;
+        } else if (s2.r > dist + s1.r) {
+            gc[0] = s2.c[0]; gc[1] = s2.c[1]; gc[2] = s2.c[2]; gr = s2.r;
+        } else {
+            const double nx = vx / dist, ny = vy / dist, nz = vz / dist;
+            const double ax = s2.c[0] + s2.r * nx, ay = s2.c[1] + s2.r * ny, az = s2.c[2] + s2.r * nz;
+            const double bx = s1.c[0] - s1.r * nx, by = s1.c[1] - s1.r * ny, bz = s1.c[2] - s1.r * nz;
+            gc[0] = 0.5 * (ax + bx); gc[1] = 0.5 * (ay + by); gc[2] = 0.5 * (az + bz);
+            gr = 0.5 * vnorm(ax - bx, ay - by, az - bz);
+        }
+        SmplxNode n;
+        std::memset(&n, 0, sizeof(n));
+        if (gr < cr) { n.c[0] = gc[0]; n.c[1] = gc[1]; n.c[2] = gc[2]; n.r = gr; }
+        else { n.c[0] = cc[0]; n.c[1] = cc[1]; n.c[2] = cc[2]; n.r = cr; }
+        n.left = li;
+        n.right = ri;
+        out.push_back(n);
+        return (int)out.size() - 1;
+    }
+};
+
+}  // namespace
+
+bool compile_robot_text(const char* text, HostModel& m)
+{
+    m = HostModel();
+    std::memset(&m.dev, 0, sizeof(m.dev));
+    std::vector<std::string> links;
+    std::vector<JointRow> joints;
+    std::vector<SphereRow> spheres;
+    std::vector<std::string> group_links, planning_joints;
+    std::vector<std::pair<std::string, std::string>> acm;
+    std::istringstream in(text);
+    std::string line;
+    int lineno = 0;
+    auto fail = [&](const std::string& s) { m.error = s; return false; };
+    while (std::getline(in, line)) {
+        ++lineno;
+        const size_t h = line.find('#');
+        if (h != std::string::npos) line.resize(h);
+        std::istringstream ls(line);
+        std::string kw;
+        if (!(ls >> kw)) continue;
+        const std::string at = "line " + std::to_string(lineno) + ": ";
+        if (kw == "robot") {
+            std::string n; ls >> n;
+        } else if (kw == "link") {
+            std::string n;
+            if (!(ls >> n)) return fail(at + "link needs a name");
+            links.push_back(n);
+        } else if (kw == "joint") {
+            JointRow j;
+            std::string type;
+            if (!(ls >> j.name >> type >> j.parent >> j.child)) return fail(at + "bad joint");
+            if (type == "fixed") j.type = SMPLX_JT_FIXED;
+            else if (type == "revolute") j.type = SMPLX_JT_REVOLUTE;
+            else if (type == "continuous") j.type = SMPLX_JT_CONTINUOUS;
+            else if (type == "prismatic") j.type = SMPLX_JT_PRISMATIC;
+            else return fail(at + "unknown joint type " + type);
+            if (!(ls >> j.xyz[0] >> j.xyz[1] >> j.xyz[2] >> j.rpy[0] >> j.rpy[1] >> j.rpy[2] >> j.axis[0] >> j.axis[1] >>
+                  j.axis[2] >> j.lo >> j.hi)) return fail(at + "bad joint numbers");
+            joints.push_back(j);
+        } else if (kw == "sphere") {
+            SphereRow s;
+            if (!(ls >> s.link >> s.name >> s.c[0] >> s.c[1] >> s.c[2] >> s.r >> s.priority)) return fail(at + "bad sphere");
+            spheres.push_back(s);
+        } else if (kw == "group") {
+            std::string n, l;
+            ls >> n;
+            while (ls >> l) group_links.push_back(l);
+        } else if (kw == "acm") {
+            std::string a, b;
+            if (!(ls >> a >> b)) return fail(at + "bad acm");
+            acm.emplace_back(a, b);
+        } else if (kw == "planning_joints") {
+            std::string j;
+            while (ls >> j) planning_joints.push_back(j);
+        } else if (kw == "planning_link") {
+            ls >> m.planning_link;
+        } else {
+            return fail(at + "unknown keyword " + kw);
+        }
+    }
+    if (links.empty()) return fail("no links");
+    auto link_index = [&](const std::string& n) {
+        for (size_t i = 0; i < links.size(); ++i) if (links[i] == n) return (int)i;
+        return -1;
+    };
+    const int nl = (int)links.size(), nj = (int)joints.size();
+    if (nj > SMPLX_MAX_JOINTS) return fail("too many joints");
+    std::vector<int> link_parent_joint(nl, -1);
+    std::vector<std::vector<int>> link_children(nl);
+    for (int j = 0; j < nj; ++j) {
+        joints[j].parent_link = link_index(joints[j].parent);
+        joints[j].child_link = link_index(joints[j].child);
+        if (joints[j].parent_link < 0 || joints[j].child_link < 0) return fail("joint " + joints[j].name + " references unknown link");
+        link_parent_joint[joints[j].child_link] = j;
+        link_children[joints[j].parent_link].push_back(j);
+    }
+    for (const SphereRow& s : spheres) if (link_index(s.link) < 0) return fail("sphere on unknown link " + s.link);
+
+    // sphere trees, per link
+    std::vector<std::vector<SmplxNode>> link_tree(nl);
+    std::vector<std::vector<SphereRow>> link_spheres(nl);
+    for (const SphereRow& s : spheres) link_spheres[link_index(s.link)].push_back(s);
+    for (int l = 0; l < nl; ++l) {
+        if (link_spheres[l].empty()) continue;
+        TreeBuilder tb(link_spheres[l]);
+        tb.build(0, (int)link_spheres[l].size());
+        link_tree[l] = tb.out;
+    }
+
+    // motion spheres, leaf joints towards the root (robot_motion_collision_model.cpp:41-275)
+    std::vector<double> origins(12 * (size_t)nj);
+    for (int j = 0; j < nj; ++j) origin_matrix(joints[j].xyz, joints[j].rpy, &origins[12 * (size_t)j]);
+    std::vector<double> k_file(nj, 0.0);
+    {
+        std::vector<int> queue;
+        std::vector<int> done_children(nj, 0);
+        for (int l = 0; l < nl; ++l)
+            if (link_children[l].empty() && link_parent_joint[l] >= 0) queue.push_back(link_parent_joint[l]);
+        std::vector<std::vector<V3>> samples(nj);
+        std::vector<double> sample_r(nj, 0.0);
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const int j = queue[head];
+            const int cl = joints[j].child_link;
+            std::vector<V3> centers;
+            std::vector<double> radii;
+            if (!link_tree[cl].empty()) {
+                const SmplxNode& root = link_tree[cl].back();
+                centers.push_back({root.c[0], root.c[1], root.c[2]});
+                radii.push_back(root.r);
+            }
+            for (int cj : link_children[cl]) {
+                if (sample_r[cj] != 0.0) {
+                    for (const V3& p : samples[cj]) {
+                        centers.push_back(apply12(&origins[12 * (size_t)cj], p));
+                        radii.push_back(sample_r[cj]);
+                    }
+                }
+            }
+            V3 mc;
+            double mr = 0.0;
+            if (!centers.empty()) {
+                for (const V3& c : centers) { mc.x = mc.x + c.x; mc.y = mc.y + c.y; mc.z = mc.z + c.z; }
+                const double n = (double)centers.size();
+                mc.x = mc.x / n; mc.y = mc.y / n; mc.z = mc.z / n;
+                for (size_t i = 0; i < centers.size(); ++i) {
+                    const double rad = vnorm(centers[i].x - mc.x, centers[i].y - mc.y, centers[i].z - mc.z) + radii[i];
+                    mr = std::max(mr, rad);
+                }
+            }
+            k_file[j] = vnorm(mc.x, mc.y, mc.z) + mr;   // |mr_center| + mr_radius (:384-389)
+            std::vector<V3>& smp = samples[j];
+            if (mr != 0.0) {
+                const double res = 2.0 * SMPLX_PI / 180.0;
+                auto rotated = [&](double val) {
+                    double R[9];
+                    angle_axis(val, joints[j].axis, R);
+                    V3 p;
+                    p.x = (R[0] * mc.x + R[1] * mc.y) + R[2] * mc.z;
+                    p.y = (R[3] * mc.x + R[4] * mc.y) + R[5] * mc.z;
+                    p.z = (R[6] * mc.x + R[7] * mc.y) + R[8] * mc.z;
+                    smp.push_back(p);
+                };
+                if (joints[j].type == SMPLX_JT_REVOLUTE) {
+                    const double span = joints[j].hi - joints[j].lo;
+                    const int count = (int)std::round(span / res) + 1;
+                    for (int i = 0; i < count; ++i) {
+                        const double alpha = (double)i / (double)(count - 1);
+                        rotated((1.0 - alpha) * joints[j].lo + alpha * joints[j].hi);
+                    }
+                } else if (joints[j].type == SMPLX_JT_CONTINUOUS) {
+                    const int count = (int)std::round(2.0 * SMPLX_PI / res);
+                    const double step = 2.0 * SMPLX_PI / count;
+                    for (int i = 0; i < count; ++i) rotated(i * step);
+                } else if (joints[j].type == SMPLX_JT_PRISMATIC) {
+                    const double span = joints[j].hi - joints[j].lo;
+                    const int count = (int)std::round(span / res) + 1;
+                    for (int i = 0; i < count; ++i) {
+                        const double alpha = (double)i / (double)(count - 1);
+                        const double val = (1.0 - alpha) * joints[j].lo + alpha * joints[j].hi;
+                        smp.push_back({mc.x + val * joints[j].axis[0], mc.y + val * joints[j].axis[1], mc.z + val * joints[j].axis[2]});
+                    }
+                } else {
+                    smp.push_back(apply12(&origins[12 * (size_t)j], mc));
+                }
+            }
+            sample_r[j] = mr;
+            const int pl = joints[j].parent_link;
+            const int pj = link_parent_joint[pl];
+            if (pj >= 0) {
+                if (++done_children[pj] == (int)link_children[pl].size()) queue.push_back(pj);
+            }
+        }
+    }
+
+    // depth-first joint order with transform slots
+    SmplxModelDev& D = m.dev;
+    std::vector<int> dfs_of_file(nj, -1);
+    int free_slot = 0, max_slots = 0;
+    bool ok = true;
+    std::function<void(int, bool)> visit = [&](int link, bool is_root) {
+        const std::vector<int>& ch = link_children[link];
+        int my_slot = -1;
+        if (!is_root && ch.size() >= 2) {
+            my_slot = free_slot++;
+            max_slots = std::max(max_slots, free_slot);
+            // the joint that produced this link is the last one emitted
+            D.joints[D.njoints - 1].save_slot = my_slot;
+        }
+        for (size_t c = 0; c < ch.size(); ++c) {
+            const int fj = ch[c];
+            if (D.njoints >= SMPLX_MAX_JOINTS) { ok = false; return; }
+            SmplxJoint& J = D.joints[D.njoints];
+            std::memcpy(J.origin, &origins[12 * (size_t)fj], sizeof(J.origin));
+            J.axis[0] = joints[fj].axis[0]; J.axis[1] = joints[fj].axis[1]; J.axis[2] = joints[fj].axis[2];
+            const double* a = joints[fj].axis;
+            if (joints[fj].type == SMPLX_JT_FIXED) J.kind = SMPLX_TK_FIXED;
+            else if (joints[fj].type == SMPLX_JT_PRISMATIC) J.kind = SMPLX_TK_PRISMATIC;
+            else if (a[0] == 1.0 && a[1] == 0.0 && a[2] == 0.0) J.kind = SMPLX_TK_REV_X;   // robot_collision_model.cpp:331-407
+            else if (a[0] == 0.0 && a[1] == 1.0 && a[2] == 0.0) J.kind = SMPLX_TK_REV_Y;
+            else if (a[0] == 0.0 && a[1] == 0.0 && a[2] == 1.0) J.kind = SMPLX_TK_REV_Z;
+            else J.kind = SMPLX_TK_REV_GENERIC;
+            J.var = -1;
+            J.src = is_root ? SMPLX_SRC_ROOT : (c == 0 ? SMPLX_SRC_RUNNING : my_slot);
+            J.save_slot = -1;
+            J.tree = -1;
+            J.on_chain = 0;
+            dfs_of_file[fj] = D.njoints;
+            m.joint_names.push_back(joints[fj].name);
+            m.joint_k.push_back(k_file[fj]);
+            m.file_joint_index.push_back(fj);
+            ++D.njoints;
+            visit(joints[fj].child_link, false);
+            if (!ok) return;
+        }
+        if (my_slot >= 0) --free_slot;
+    };
+    visit(0, true);
+    if (!ok) return fail("too many joints");
+    if (D.njoints != nj) return fail("some joints are not reachable from the root link " + links[0]);
+    if (max_slots > SMPLX_MAX_SLOTS) return fail("kinematic tree branches too deeply for SMPLX_MAX_SLOTS");
+    D.nslots = max_slots;
+
+    // planning variables
+    D.nvars = (int)planning_joints.size();
+    if (D.nvars > SMPLX_MAX_VARS) return fail("too many planning variables");
+    for (int v = 0; v < D.nvars; ++v) {
+        int fj = -1;
+        for (int j = 0; j < nj; ++j) if (joints[j].name == planning_joints[v]) fj = j;
+        if (fj < 0 || joints[fj].type == SMPLX_JT_FIXED) return fail("planning joint not found or fixed: " + planning_joints[v]);
+        D.joints[dfs_of_file[fj]].var = v;
+        const bool cont = joints[fj].type == SMPLX_JT_CONTINUOUS;
+        D.var_type[v] = joints[fj].type;
+        D.var_min[v] = cont ? -SMPLX_PI : joints[fj].lo;   // kdl_robot_model.cpp:299-303
+        D.var_max[v] = cont ? SMPLX_PI : joints[fj].hi;
+        D.var_min_norm[v] = smplx_normalize_angle(D.var_min[v]);
+        D.var_k[v] = k_file[fj];
+        m.var_names.push_back(planning_joints[v]);
+    }
+
+    // group trees in group order
+    std::vector<int> link_tree_index(nl, -1);
+    std::vector<int> group_link_ids;
+    for (const std::string& gl : group_links) {
+        const int l = link_index(gl);
+        if (l < 0) return fail("group link unknown: " + gl);
+        group_link_ids.push_back(l);
+        if (link_tree[l].empty()) continue;
+        if (D.ntrees >= SMPLX_MAX_TREES) return fail("too many sphere trees");
+        if (D.nnodes + (int)link_tree[l].size() > SMPLX_MAX_NODES) return fail("too many sphere-tree nodes");
+        const int t = D.ntrees++;
+        link_tree_index[l] = t;
+        D.tree_first[t] = D.nnodes;
+        for (const SmplxNode& n : link_tree[l]) {
+            SmplxNode g = n;
+            if (g.left >= 0) { g.left += D.tree_first[t]; g.right += D.tree_first[t]; }
+            D.nodes[D.nnodes++] = g;
+        }
+        D.tree_first[t + 1] = D.nnodes;
+        const int pj = link_parent_joint[l];
+        if (pj < 0) return fail("spheres on the root link are not supported");
+        D.tree_joint[t] = dfs_of_file[pj];
+        D.joints[dfs_of_file[pj]].tree = t;
+    }
+    for (int l = 0; l < nl; ++l)
+        if (!link_tree[l].empty() && link_tree_index[l] < 0)
+            return fail("link " + links[l] + " has spheres but is outside the group (voxelised links are out of scope)");
+
+    // checked pairs (self_collision_model.cpp:1233-1268) with adjacent links allowed (:280-312)
+    std::vector<std::vector<char>> allowed(nl, std::vector<char>(nl, 0));
+    for (int l = 0; l < nl; ++l) {
+        const int pj = link_parent_joint[l];
+        if (pj >= 0) { allowed[l][joints[pj].parent_link] = 1; allowed[joints[pj].parent_link][l] = 1; }
+    }
+    for (const auto& pr : acm) {
+        const int a = link_index(pr.first), b = link_index(pr.second);
+        if (a < 0 || b < 0) return fail("acm references unknown link");
+        allowed[a][b] = allowed[b][a] = 1;
+    }
+    for (size_t i = 0; i < group_link_ids.size(); ++i) {
+        if (link_tree_index[group_link_ids[i]] < 0) continue;
+        for (size_t j = i + 1; j < group_link_ids.size(); ++j) {
+            if (link_tree_index[group_link_ids[j]] < 0) continue;
+            if (allowed[group_link_ids[i]][group_link_ids[j]]) continue;
+            if (D.npairs >= SMPLX_MAX_PAIRS) return fail("too many checked link pairs");
+            D.pair_a[D.npairs] = link_tree_index[group_link_ids[i]];
+            D.pair_b[D.npairs] = link_tree_index[group_link_ids[j]];
+            ++D.npairs;
+        }
+    }
+
+    // chain to the planning link
+    int l = link_index(m.planning_link);
+    if (l < 0) return fail("planning link unknown: " + m.planning_link);
+    while (link_parent_joint[l] >= 0) {
+        const int fj = link_parent_joint[l];
+        D.joints[dfs_of_file[fj]].on_chain = 1;
+        ++D.nchain;
+        l = joints[fj].parent_link;
+    }
+    return true;
+}
+
+int sphere_threshold(double radius, double padding, double res, int dmax_sqrd)
+{
+    const double er = radius + padding;
+    const double need = er * er;
+    for (int i = 0; i <= dmax_sqrd; ++i) {
+        const double d = res * std::sqrt((double)i);   // distance_map.hpp:142
+        if (d * d >= need) return i;                    // distance_map_interface.h:113-114
+    }
+    return dmax_sqrd + 1;
+}
+
+int wall_threshold(double radius, double res, int dmax_sqrd)
+{
+    int best = -1;
+    for (int i = 0; i <= dmax_sqrd; ++i) {
+        if (res * std::sqrt((double)i) <= radius) best = i; else break;
+    }
+    return best;
+}
+
+bool load_mprim_text(const char* text, const double* resolutions, int nvars, HostActions& a)
+{
+    std::memset(&a.dev, 0, sizeof(a.dev));
+    auto fail = [&](const std::string& s) { a.error = s; return false; };
+    SmplxActionsDev& D = a.dev;
+    // the three adaptive slots always come first (manip_lattice_action_space.cpp:233-256)
+    const int snap_types[3] = {SMPLX_MP_SNAP_RPY, SMPLX_MP_SNAP_XYZ, SMPLX_MP_SNAP_XYZ_RPY};
+    for (int i = 0; i < 3; ++i) {
+        D.type[D.nprims] = snap_types[i];
+        D.cost[D.nprims] = (int)(1000 * 0.5);
+        ++D.nprims;
+    }
+    std::istringstream in(text);
+    std::string hdr;
+    int nrows = 0, ncols = 0, nshort = 0;
+    if (!(in >> hdr) || hdr != "Motion_Primitives(degrees):") return fail("first token must be 'Motion_Primitives(degrees):'");
+    if (!(in >> nrows >> ncols >> nshort)) return fail("bad header counts");
+    const bool fork_rows = ncols == nvars + 2;
+    if (!fork_rows && ncols != nvars) return fail("column count does not match the planning variables");
+    for (int r = 0; r < nrows; ++r) {
+        double d[SMPLX_MAX_VARS];
+        for (int v = 0; v < nvars; ++v) {
+            double x;
+            if (!(in >> x)) return fail("row too short");
+            d[v] = x * resolutions[v];   // :172
+        }
+        int group = -1;
+        double weight = 1.0;
+        if (fork_rows && !(in >> group >> weight)) return fail("row lacks group/weight");
+        const int type = r < nrows - nshort ? SMPLX_MP_LONG : SMPLX_MP_SHORT;
+        for (int sign = 0; sign < 2; ++sign) {   // each row also adds its converse (:218-225)
+            if (D.nprims >= SMPLX_MAX_PRIMS) return fail("too many motion primitives");
+            D.type[D.nprims] = type;
+            D.cost[D.nprims] = (int)(1000 * weight);   // manip_lattice.cpp:1436
+            for (int v = 0; v < nvars; ++v) D.delta[D.nprims][v] = sign ? d[v] * -1.0 : d[v];
+            ++D.nprims;
+        }
+    }
+    return true;
+}
+
+void fill_discretization(SmplxModelDev& m, const double* resolutions)
+{
+    for (int v = 0; v < m.nvars; ++v) {
+        if (m.var_type[v] == SMPLX_JT_CONTINUOUS) {
+            m.coord_vals[v] = (int)std::round((2.0 * SMPLX_PI) / resolutions[v]);
+            m.coord_delta[v] = (2.0 * SMPLX_PI) / (double)m.coord_vals[v];
+        } else {
+            const double span = std::fabs(m.var_max[v] - m.var_min[v]);
+            m.coord_vals[v] = std::max(1, (int)std::round(span / resolutions[v]));
+            m.coord_delta[v] = span / (double)m.coord_vals[v];
+        }
+    }
+}
+
+}  // namespace smplx

@@ -1,0 +1,339 @@
+"""Seeded synthetic inputs for the ARA* state-expansion path.
+
+Nothing here is on the hot path: it builds the *inputs* the path consumes --
+a plain-text robot model (replaces URDF + collision-model YAML, which need
+urdf/XmlRpc), a motion-primitive file in the reference's own format
+(smpl/src/graph/manip_lattice_action_space.cpp:89-103), and a dense squared
+distance grid laid out like smpl's Grid3 (x-major, z fastest) with border cells
+acting as obstacles (smpl/include/smpl/distance_map/detail/distance_map.hpp:560-606).
+
+The distance field is an exact Euclidean transform (scipy) capped at
+ceil(max_dist/res)^2; the reference's incremental propagation
+(distance_map.hpp:627-839) is SURVEY row N1 ("next") and is an *input* to the
+path, so both the oracle and the HIP engine are always fed the same array.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+DEG = math.pi / 180.0
+
+
+# ----------------------------------------------------------------------------
+# robots
+# ----------------------------------------------------------------------------
+
+def arm7_text(prefix: str = "", mount=(0.0, -0.188, 0.80), with_header: bool = True,
+              parent: str = "base_link") -> str:
+    """7-R arm, PR2-right-arm-like topology: Z,Y,X,Y,X,Y,X axes, two continuous rolls,
+    sphere trees of 1,4,7,3,2,2,2,2 leaves (23 leaves), gripper fingers on fixed joints."""
+    p = prefix
+    L = []
+    if with_header:
+        L += ["robot arm7", "link base_link"]
+    for n in ["shoulder_base", "shoulder_pan_link", "shoulder_lift_link", "upper_arm_link", "elbow_link",
+              "forearm_link", "wrist_flex_link", "gripper_palm_link", "l_finger_link", "l_finger_tip_link",
+              "r_finger_link", "r_finger_tip_link", "tool_link"]:
+        L.append(f"link {p}{n}")
+    J = "joint {n} {t} {pa} {ch}  {o[0]} {o[1]} {o[2]}  {r[0]} {r[1]} {r[2]}  {a[0]} {a[1]} {a[2]}  {lo} {hi}"
+
+    def joint(n, t, pa, ch, o=(0, 0, 0), r=(0, 0, 0), a=(0, 0, 1), lo=0.0, hi=0.0):
+        pa_name = parent if pa == parent else p + pa
+        L.append(J.format(n=p + n, t=t, pa=pa_name, ch=p + ch, o=o, r=r, a=a, lo=lo, hi=hi))
+
+    joint("mount", "fixed", parent, "shoulder_base", o=mount)
+    joint("shoulder_pan", "revolute", "shoulder_base", "shoulder_pan_link", a=(0, 0, 1), lo=-2.2, hi=0.7)
+    joint("shoulder_lift", "revolute", "shoulder_pan_link", "shoulder_lift_link", o=(0.10, 0, 0), a=(0, 1, 0), lo=-0.5, hi=1.3)
+    joint("upper_arm_roll", "revolute", "shoulder_lift_link", "upper_arm_link", a=(1, 0, 0), lo=-3.9, hi=0.8)
+    joint("elbow_flex", "revolute", "upper_arm_link", "elbow_link", o=(0.40, 0, 0), a=(0, 1, 0), lo=-2.3, hi=0.0)
+    joint("forearm_roll", "continuous", "elbow_link", "forearm_link", a=(1, 0, 0))
+    joint("wrist_flex", "revolute", "forearm_link", "wrist_flex_link", o=(0.32, 0, 0), a=(0, 1, 0), lo=-2.1, hi=0.0)
+    joint("wrist_roll", "continuous", "wrist_flex_link", "gripper_palm_link", a=(1, 0, 0))
+    joint("l_finger", "fixed", "gripper_palm_link", "l_finger_link", o=(0.077, 0.01, 0))
+    joint("l_finger_tip", "fixed", "l_finger_link", "l_finger_tip_link", o=(0.09, 0.005, 0))
+    joint("r_finger", "fixed", "gripper_palm_link", "r_finger_link", o=(0.077, -0.01, 0))
+    joint("r_finger_tip", "fixed", "r_finger_link", "r_finger_tip_link", o=(0.09, -0.005, 0))
+    joint("tool", "fixed", "gripper_palm_link", "tool_link", o=(0.18, 0, 0))
+
+    def sph(link, name, x, y, z, r, pr=1):
+        L.append(f"sphere {p}{link} {p}{name} {x} {y} {z} {r} {pr}")
+
+    sph("shoulder_pan_link", "sh0", 0.11, 0.0, -0.035, 0.15, 5)
+    sph("upper_arm_link", "ua0", 0.17, 0.0, -0.012, 0.105, 4)
+    sph("upper_arm_link", "ua1", 0.255, 0.0, -0.03, 0.08, 4)
+    sph("upper_arm_link", "ua2", 0.325, 0.0, -0.03, 0.08, 4)
+    sph("upper_arm_link", "ua3", 0.40, 0.0, 0.0, 0.10, 2)
+    sph("forearm_link", "fa0", 0.125, 0.0, 0.004, 0.075, 2)
+    sph("forearm_link", "fa1", 0.195, 0.024, -0.01, 0.055, 3)
+    sph("forearm_link", "fa2", 0.195, -0.024, -0.01, 0.055, 3)
+    sph("forearm_link", "fa3", 0.26, 0.027, -0.014, 0.05, 3)
+    sph("forearm_link", "fa4", 0.26, -0.027, -0.014, 0.05, 3)
+    sph("forearm_link", "fa5", 0.315, 0.022, -0.005, 0.05, 3)
+    sph("forearm_link", "fa6", 0.315, -0.022, -0.005, 0.05, 3)
+    sph("gripper_palm_link", "gr0", 0.07, -0.017, 0.0, 0.04, 2)
+    sph("gripper_palm_link", "gr1", 0.07, 0.017, 0.0, 0.04, 2)
+    sph("gripper_palm_link", "gr2", 0.09, 0.0, 0.0, 0.04, 2)
+    sph("l_finger_link", "lf0", 0.03, 0.024, 0.0, 0.038, 1)
+    sph("l_finger_link", "lf1", 0.078, 0.017, 0.0, 0.034, 1)
+    sph("r_finger_link", "rf0", 0.03, -0.024, 0.0, 0.038, 1)
+    sph("r_finger_link", "rf1", 0.078, -0.017, 0.0, 0.034, 1)
+    sph("l_finger_tip_link", "lt0", 0.015, -0.005, 0.0, 0.028, 1)
+    sph("l_finger_tip_link", "lt1", 0.034, -0.005, 0.0, 0.02, 1)
+    sph("r_finger_tip_link", "rt0", 0.015, 0.005, 0.0, 0.028, 1)
+    sph("r_finger_tip_link", "rt1", 0.034, 0.005, 0.0, 0.02, 1)
+    return "\n".join(L) + "\n"
+
+
+_ARM_SPHERE_LINKS = ["shoulder_pan_link", "upper_arm_link", "forearm_link", "gripper_palm_link",
+                     "l_finger_link", "r_finger_link", "l_finger_tip_link", "r_finger_tip_link"]
+_ARM_JOINTS = ["shoulder_pan", "shoulder_lift", "upper_arm_roll", "elbow_flex", "forearm_roll",
+               "wrist_flex", "wrist_roll"]
+
+
+def _arm_acm(p: str) -> list[str]:
+    """Pairs that are never checked (an SRDF-like 'never in collision' list) besides adjacent links."""
+    a = []
+
+    def allow(x, y):
+        a.append(f"acm {p}{x} {p}{y}")
+
+    allow("shoulder_pan_link", "upper_arm_link")
+    allow("upper_arm_link", "forearm_link")
+    allow("forearm_link", "gripper_palm_link")
+    for f in ["l_finger_link", "r_finger_link", "l_finger_tip_link", "r_finger_tip_link"]:
+        allow("forearm_link", f)
+    allow("gripper_palm_link", "l_finger_tip_link")
+    allow("gripper_palm_link", "r_finger_tip_link")
+    allow("l_finger_link", "r_finger_link")
+    allow("l_finger_link", "r_finger_tip_link")
+    allow("r_finger_link", "l_finger_tip_link")
+    allow("l_finger_tip_link", "r_finger_tip_link")
+    return a
+
+
+def arm7_robot() -> str:
+    t = arm7_text()
+    t += "group arm " + " ".join(_ARM_SPHERE_LINKS) + "\n"
+    t += "\n".join(_arm_acm("")) + "\n"
+    t += "planning_joints " + " ".join(_ARM_JOINTS) + "\n"
+    t += "planning_link tool_link\n"
+    return t
+
+
+def dual_arm14_robot() -> str:
+    """Two arm7 chains on a common base (config 5): 14 variables, 46 leaves, inter-arm pairs checked."""
+    t = "robot dual_arm14\nlink base_link\n"
+    t += arm7_text("r_", mount=(0.0, -0.188, 0.80), with_header=False)
+    t += arm7_text("l_", mount=(0.0, 0.188, 0.80), with_header=False)
+    t += "group arms " + " ".join(["r_" + l for l in _ARM_SPHERE_LINKS] + ["l_" + l for l in _ARM_SPHERE_LINKS]) + "\n"
+    t += "\n".join(_arm_acm("r_") + _arm_acm("l_")) + "\n"
+    # the two shoulders sit next to each other on the torso and always overlap
+    t += "acm r_shoulder_pan_link l_shoulder_pan_link\n"
+    t += "planning_joints " + " ".join(["r_" + j for j in _ARM_JOINTS] + ["l_" + j for j in _ARM_JOINTS]) + "\n"
+    t += "planning_link r_tool_link\n"
+    return t
+
+
+def mprim_text(nvars: int, long_joints, short_joints, long_cells: int = 7, short_cells: int = 4) -> str:
+    """Upstream .mprim layout (smpl_test/config/pr2.mprim has 4 long rows of 7 and 7 short rows of 4)."""
+    rows = []
+    for j in long_joints:
+        r = [0] * nvars
+        r[j] = long_cells
+        rows.append(r)
+    for j in short_joints:
+        r = [0] * nvars
+        r[j] = short_cells
+        rows.append(r)
+    out = [f"Motion_Primitives(degrees): {len(rows)} {nvars} {len(short_joints)}"]
+    out += [" ".join(str(v) for v in r) for r in rows]
+    return "\n".join(out) + "\n"
+
+
+# ----------------------------------------------------------------------------
+# scenes / grids
+# ----------------------------------------------------------------------------
+
+@dataclass
+class Grid:
+    origin: tuple
+    dims: tuple          # interior cells (nx, ny, nz)
+    res: float
+    max_dist: float
+    d2: np.ndarray       # int32 [nx, ny, nz], squared cell distance to nearest obstacle/border, capped
+
+    @property
+    def dmax_int(self) -> int:
+        return int(math.ceil(self.max_dist * (1.0 / self.res)))
+
+
+def world_to_grid(origin, res, w):
+    """smpl/include/smpl/distance_map/detail/distance_map.hpp:520-527 (vectorised)."""
+    inv = 1.0 / res
+    return ((inv * (np.asarray(w, dtype=np.float64) - (np.asarray(origin) - res)) + 0.5).astype(np.int64) - 1)
+
+
+def box_cells(origin, res, dims, center, size):
+    """Cells whose centres fall inside an axis-aligned box (minimal restatement of
+    smpl/src/geometry/voxelize.cpp:673-735 VoxelizeBox for scene building only)."""
+    lo = np.asarray(center) - 0.5 * np.asarray(size)
+    hi = np.asarray(center) + 0.5 * np.asarray(size)
+    clo = np.maximum(world_to_grid(origin, res, lo), 0)
+    chi = np.minimum(world_to_grid(origin, res, hi), np.asarray(dims) - 1)
+    return clo, chi
+
+
+def build_grid(origin, dims, res, max_dist, boxes) -> Grid:
+    from scipy import ndimage
+
+    nx, ny, nz = dims
+    occ = np.zeros((nx + 2, ny + 2, nz + 2), dtype=bool)
+    occ[0, :, :] = occ[-1, :, :] = True
+    occ[:, 0, :] = occ[:, -1, :] = True
+    occ[:, :, 0] = occ[:, :, -1] = True
+    for (c, s) in boxes:
+        clo, chi = box_cells(origin, res, dims, c, s)
+        if np.all(chi >= clo):
+            occ[clo[0] + 1:chi[0] + 2, clo[1] + 1:chi[1] + 2, clo[2] + 1:chi[2] + 2] = True
+    dmax = int(math.ceil(max_dist * (1.0 / res)))
+    # exact squared distances from the feature transform (integer arithmetic)
+    idx = ndimage.distance_transform_edt(~occ, return_distances=False, return_indices=True)
+    d2 = np.zeros(occ.shape, dtype=np.int64)
+    for a in range(3):
+        g = np.arange(occ.shape[a]).reshape([-1 if i == a else 1 for i in range(3)])
+        d = idx[a].astype(np.int64) - g
+        d2 += d * d
+    del idx
+    d2 = np.minimum(d2, dmax * dmax).astype(np.int32)
+    return Grid(tuple(origin), tuple(dims), res, max_dist, np.ascontiguousarray(d2[1:-1, 1:-1, 1:-1]))
+
+
+def random_boxes(rng: np.random.Generator, n, origin, dims, res, keep_clear, clear_radius, edge=(0.05, 0.30)):
+    """n random boxes, rejecting those within clear_radius of any keep_clear point."""
+    size = np.asarray(dims) * res
+    boxes = []
+    keep_clear = np.asarray(keep_clear, dtype=np.float64).reshape(-1, 3)
+    while len(boxes) < n:
+        e = rng.uniform(edge[0], edge[1], size=3)
+        c = np.asarray(origin) + rng.uniform(0.0, 1.0, size=3) * size
+        half_diag = 0.5 * float(np.linalg.norm(e))
+        if keep_clear.size and np.min(np.linalg.norm(keep_clear - c, axis=1)) < clear_radius + half_diag:
+            continue
+        boxes.append((tuple(c), tuple(e)))
+    return boxes
+
+
+@dataclass
+class PlanningParams:
+    resolutions: list
+    bfs_radius: float = 0.02          # smpl_test/src/call_planner.cpp:1715
+    cost_per_cell: int = 250
+    use_short: bool = True            # smpl_test/config/pr2_right_arm.yaml use_short_dist_mprims
+    short_thresh: float = 0.4
+    use_xyzrpy_snap: bool = True
+    xyzrpy_thresh: float = 0.04
+    xy_rotate_by_var3: bool = False   # [FORK] switch; parity runs cover both
+    use_long_and_short: bool = False
+    eps0: float = 5.0
+    eps_final: float = 1.0
+    eps_delta: float = 1.0
+
+
+@dataclass
+class Config:
+    name: str
+    robot_text: str
+    mprim: str
+    grid: Grid
+    params: PlanningParams
+    start: list
+    goal: list
+    goal_tol: list = field(default_factory=list)
+    boxes: list = field(default_factory=list)
+
+
+ARM7_START = [0.0, 0.0, 0.0, -1.1356, 0.0, -1.05, 0.0]   # smpl_test/experiments/pr2_goal.yaml
+# lattice-reachable goal: joints 0-3 any cell, joints 4-6 a multiple of 4 cells from the start
+ARM7_GOAL_CELLS = [-42, 21, -35, 14, 8, 12, -16]
+TABLETOP = ((0.55, 0.0, 0.6), (0.4, 1.5, 0.02))             # smpl_test/env/tabletop.env
+
+
+def _arm7_goal():
+    return [ARM7_START[i] + ARM7_GOAL_CELLS[i] * DEG for i in range(7)]
+
+
+def config1(n: int = 128) -> Config:
+    """SURVEY 8d cfg 1: 7-DOF arm, 128^3 @ 0.02 m, tabletop, eps 100 -> 1 (CPU plumbing case)."""
+    origin = (-0.75, -1.28, 0.0)
+    grid = build_grid(origin, (n, n, n), 0.02, 0.4, [TABLETOP])
+    p = PlanningParams([DEG] * 7, eps0=100.0)
+    return Config("cfg1", arm7_robot(), mprim_text(7, range(4), range(7)), grid, p, list(ARM7_START), _arm7_goal(),
+                  [3.0 * DEG] * 7, [TABLETOP])
+
+
+def config2(n: int = 256, nboxes: int = 64, seed: int = 2) -> Config:
+    """SURVEY 8d cfg 2: same arm, 256^3 @ 0.02 m, tabletop + 64 random boxes (seed 2), eps 5 -> 1."""
+    res = 0.02
+    size = n * res
+    origin = (0.5 - 0.5 * size, -0.5 * size, 0.8 - 0.25 * size)
+    rng = np.random.default_rng(seed)
+    # keep the arm's swept volume between start and goal roughly clear
+    clear = [(0.0, -0.188, 0.8), (0.45, -0.188, 0.8), (0.6, -0.3, 0.9), (0.5, -0.6, 0.95), (0.3, -0.7, 1.0)]
+    boxes = [TABLETOP] + random_boxes(rng, nboxes, origin, (n, n, n), res, clear, 0.30)
+    grid = build_grid(origin, (n, n, n), res, 0.4, boxes)
+    p = PlanningParams([DEG] * 7, eps0=5.0)
+    return Config("cfg2", arm7_robot(), mprim_text(7, range(4), range(7)), grid, p, list(ARM7_START), _arm7_goal(),
+                  [3.0 * DEG] * 7, boxes)
+
+
+def config_small(n: int = 64, seed: int = 7, nboxes: int = 6) -> Config:
+    """Small test scene (64^3 @ 0.04 m): the oracle finishes a full ARA* query in well under a second."""
+    res = 0.04
+    size = n * res
+    origin = (0.5 - 0.5 * size, -0.5 * size, 0.8 - 0.5 * size)
+    rng = np.random.default_rng(seed)
+    clear = [(0.0, -0.188, 0.8), (0.45, -0.188, 0.8), (0.6, -0.3, 0.9), (0.5, -0.6, 0.95), (0.3, -0.7, 1.0)]
+    boxes = [TABLETOP] + random_boxes(rng, nboxes, origin, (n, n, n), res, clear, 0.30)
+    grid = build_grid(origin, (n, n, n), res, 0.4, boxes)
+    p = PlanningParams([DEG] * 7, eps0=5.0, bfs_radius=0.04)
+    return Config("small", arm7_robot(), mprim_text(7, range(4), range(7)), grid, p, list(ARM7_START), _arm7_goal(),
+                  [3.0 * DEG] * 7, boxes)
+
+
+def config5(n: int = 512, nboxes: int = 128, seed: int = 5) -> Config:
+    """SURVEY 8d cfg 5: 14-DOF dual arm, 512^3 @ 0.01 m, tabletop + 128 boxes, eps 10 -> 1."""
+    res = 0.01
+    size = n * res
+    origin = (0.5 - 0.5 * size, -0.5 * size, 0.8 - 0.4 * size)
+    rng = np.random.default_rng(seed)
+    clear = [(0.0, -0.188, 0.8), (0.0, 0.188, 0.8), (0.45, -0.188, 0.8), (0.45, 0.188, 0.8), (0.6, -0.3, 0.9),
+             (0.6, 0.3, 0.9), (0.5, -0.6, 0.95), (0.5, 0.6, 0.95)]
+    boxes = [TABLETOP] + random_boxes(rng, nboxes, origin, (n, n, n), res, clear, 0.30, edge=(0.05, 0.25))
+    grid = build_grid(origin, (n, n, n), res, 0.4, boxes)
+    p = PlanningParams([DEG] * 14, eps0=10.0, bfs_radius=0.02)
+    start = list(ARM7_START) + list(ARM7_START)
+    start[7] = 0.0
+    goal = _arm7_goal() + [ARM7_START[i] - ARM7_GOAL_CELLS[i] * DEG * (1 if i in (1, 3, 5) else -1) for i in range(7)]
+    # mirror the left arm's pan/roll so it reaches to its own side
+    goal[7] = ARM7_START[0] + 28 * DEG
+    goal[9] = ARM7_START[2] + 35 * DEG
+    goal[11] = ARM7_START[4] - 8 * DEG
+    goal[13] = ARM7_START[6] + 16 * DEG
+    return Config("cfg5", dual_arm14_robot(), mprim_text(14, range(14), range(14)), grid, p, start, goal,
+                  [3.0 * DEG] * 14, boxes)
+
+
+def random_states(cfg_limits, n: int, seed: int = 12345) -> np.ndarray:
+    """n joint states uniform within limits (scheme of
+    sbpl_collision_checking_test/src/benchmark_cc.cpp:280-301); continuous joints in [-pi, pi]."""
+    rng = np.random.default_rng(seed)
+    lo = np.array([l for (l, h) in cfg_limits])
+    hi = np.array([h for (l, h) in cfg_limits])
+    return lo + rng.uniform(size=(n, len(cfg_limits))) * (hi - lo)
+
+
+ARM7_LIMITS = [(-2.2, 0.7), (-0.5, 1.3), (-3.9, 0.8), (-2.3, 0.0), (-math.pi, math.pi), (-2.1, 0.0),
+               (-math.pi, math.pi)]
