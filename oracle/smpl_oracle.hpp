@@ -870,6 +870,7 @@ struct CollisionSpace {
     std::vector<int> planning_to_var;  // planning joint i -> model var index
     std::vector<double> joint_vars;    // full model variable vector
     std::vector<std::pair<int, int>> checked_pairs;  // spheres-model index pairs
+    std::vector<int> chain_order;                    // group trees in depth-first link order
     double padding = 0.0;
     TraversalOrder order = ORDER_REFERENCE;
 
@@ -878,6 +879,19 @@ struct CollisionSpace {
     {
         for (const std::string& j : planning_joints) planning_to_var.push_back(m->varIndex(j));
         joint_vars.assign(m->var_names.size(), 0.0);
+        // ORDER_CHAIN: group trees in depth-first link order (children in file order)
+        {
+            std::vector<int> stack{0};
+            while (!stack.empty()) {
+                const int l = stack.back();
+                stack.pop_back();
+                const int sm = m->link_spheres_model[l];
+                if (sm >= 0 && std::find(m->group_spheres_models.begin(), m->group_spheres_models.end(), sm) != m->group_spheres_models.end())
+                    chain_order.push_back(sm);
+                const auto& ch = m->link_child_joints[l];
+                for (auto it = ch.rbegin(); it != ch.rend(); ++it) stack.push_back(m->joint_child_link[*it]);
+            }
+        }
         // self_collision_model.cpp:1233-1268 updateRobotCheckedSphereIndices
         const auto& gl = m->group_links;
         for (size_t l1 = 0; l1 < gl.size(); ++l1) {
@@ -923,7 +937,7 @@ struct CollisionSpace {
             for (int sm : rcm->group_spheres_models) q.push_back({sm, rcm->spheres_models[sm].root()});
             return run();
         }
-        for (int sm : rcm->group_spheres_models) {
+        for (int sm : chain_order) {
             q.clear();
             q.push_back({sm, rcm->spheres_models[sm].root()});
             if (!run()) return false;

@@ -257,7 +257,7 @@ class Config:
 
 ARM7_START = [0.0, 0.0, 0.0, -1.1356, 0.0, -1.05, 0.0]   # smpl_test/experiments/pr2_goal.yaml
 # lattice-reachable goal: joints 0-3 any cell, joints 4-6 a multiple of 4 cells from the start
-ARM7_GOAL_CELLS = [-42, 21, -35, 14, 8, 12, -16]
+ARM7_GOAL_CELLS = [-88, 4, 29, -22, -32, -52, 40]
 TABLETOP = ((0.55, 0.0, 0.6), (0.4, 1.5, 0.02))             # smpl_test/env/tabletop.env
 
 
@@ -298,8 +298,9 @@ def config_small(n: int = 64, seed: int = 7, nboxes: int = 6) -> Config:
     clear = [(0.0, -0.188, 0.8), (0.45, -0.188, 0.8), (0.6, -0.3, 0.9), (0.5, -0.6, 0.95), (0.3, -0.7, 1.0)]
     boxes = [TABLETOP] + random_boxes(rng, nboxes, origin, (n, n, n), res, clear, 0.30)
     grid = build_grid(origin, (n, n, n), res, 0.4, boxes)
-    p = PlanningParams([DEG] * 7, eps0=5.0, bfs_radius=0.04)
-    return Config("small", arm7_robot(), mprim_text(7, range(4), range(7)), grid, p, list(ARM7_START), _arm7_goal(),
+    p = PlanningParams([DEG] * 7, eps0=5.0, bfs_radius=0.04, cost_per_cell=500)
+    goal = [ARM7_START[i] + c * DEG for i, c in enumerate([-49, 7, 21, -14, -8, -12, 16])]
+    return Config("small", arm7_robot(), mprim_text(7, range(4), range(7)), grid, p, list(ARM7_START), goal,
                   [3.0 * DEG] * 7, boxes)
 
 

@@ -1,0 +1,191 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for every integer/boolean/index result (validity bits, waypoint counts, lookup counts,
+coordinates, heuristic values, state ids, expansion order, path cost) and -- because of the arithmetic
+contract -- bit-exact for the double results too (sphere positions, successor
+joint values); north_star only asks 1e-6 for floats, asserted as well.
+"""
+import numpy as np
+import pytest
+
+from smpl_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+DEG = scenes.DEG
+
+
+@pytest.fixture(scope="module")
+def ctx(small_cfg):
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    if capi.lib().smplx_device_count() == 0:
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    o = Oracle(small_cfg)
+    o.set_order(chain=True)   # the kernel walks the sphere trees link by link (same booleans, see oracle)
+    s = capi.Space.from_config(small_cfg)
+    o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    return small_cfg, o, s
+
+
+def _random_states(n, seed):
+    return scenes.random_states(scenes.ARM7_LIMITS, n, seed)
+
+
+def test_goal_pose_and_bfs_grid(ctx):
+    cfg, o, s = ctx
+    assert np.array_equal(o.goal_pose(), s.goal_pose())
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+
+
+def test_sphere_positions_bitwise(ctx):
+    cfg, o, s = ctx
+    Q = _random_states(64, 1)
+    got = s.sphere_positions(Q)
+    for i in range(Q.shape[0]):
+        exp = o.sphere_positions(Q[i], s.model.nnodes)
+        assert np.array_equal(exp, got[i]), f"state {i}"
+        assert np.max(np.abs(exp - got[i])) <= 1e-6
+
+
+def test_state_valid_batch(ctx):
+    cfg, o, s = ctx
+    Q = _random_states(2000, 2)
+    ok, lk = s.state_valid_batch(Q)
+    exp = [o.state_valid(q) for q in Q]
+    assert np.array_equal(ok.astype(bool), np.array([e[0] for e in exp]))
+    assert np.array_equal(lk, np.array([e[1] for e in exp]))
+    assert 0.05 < ok.mean() < 0.95   # the sample exercises both outcomes
+
+
+def test_edge_valid_batch_short_and_long(ctx):
+    cfg, o, s = ctx
+    rng = np.random.default_rng(3)
+    A = _random_states(1500, 3)
+    B = A.copy()
+    # primitive-sized moves on one joint
+    j = rng.integers(0, 7, size=A.shape[0])
+    B[np.arange(A.shape[0]), j] += rng.choice([-7, -4, 4, 7], size=A.shape[0]) * DEG
+    # long edges (stride-5 waypoint order), including wrap-around of the continuous joints
+    B[1000:] = _random_states(500, 4)
+    B[1400:, 4] += 2.5 * np.pi
+    B[1450:] = A[1450:]          # zero motion: no waypoints
+    ok, lk, w = s.edge_valid_batch(A, B)
+    eo, el = o.edge_valid_batch(A, B)
+    ew = np.array([o.waypoint_count(a, b) for a, b in zip(A, B)])
+    assert np.array_equal(w, ew)
+    assert np.array_equal(ok, eo)
+    assert np.array_equal(lk, el)
+    assert w.max() > 5 and (w == 0).sum() == 50
+
+
+def test_interpolate_matches_oracle_waypoints(ctx):
+    cfg, o, s = ctx
+    a = np.array(cfg.start); b = a.copy(); b[0] += 7 * DEG
+    pts, n = s.interpolate(a, b)
+    assert n == o.waypoint_count(a, b)
+    assert np.array_equal(pts[0], a)
+
+
+def test_heuristic_batch(ctx):
+    cfg, o, s = ctx
+    Q = _random_states(1000, 5)
+    h, xyz = s.heuristic_batch(Q)
+    assert np.array_equal(h, np.array([o.heuristic_q(q) for q in Q]))
+    assert np.array_equal(xyz, np.array([o.planning_fk(q) for q in Q]))
+    assert len(np.unique(h)) > 10
+
+
+def _compare_expand(o, s, Q):
+    got = s.expand_batch(Q)
+    for i, q in enumerate(Q):
+        exp = o.eval_state(q)
+        assert np.array_equal(exp["flags"], got["flags"][i]), f"flags of state {i}"
+        valid = (exp["flags"] & 1) != 0
+        evaluated = (exp["flags"] & 0x10) == 0
+        assert np.array_equal(exp["coord"][valid], got["coord"][i][valid])
+        assert np.array_equal(exp["q"][evaluated], got["q"][i][evaluated])
+        assert np.array_equal(exp["h"][valid], got["h"][i][valid])
+        assert np.array_equal(exp["cost"][valid], got["cost"][i][valid])
+        assert np.array_equal(exp["lookups"], got["lookups"][i]), f"lookups of state {i}"
+    return got
+
+
+def test_expand_batch_random_states(ctx):
+    cfg, o, s = ctx
+    Q = _random_states(300, 6)
+    got = _compare_expand(o, s, Q)
+    f = got["flags"]
+    assert (f & 1).sum() > 100 and (f & 0x40).sum() > 100 and (f & 0x20).sum() > 10
+
+
+def test_expand_batch_near_goal_and_start(ctx):
+    cfg, o, s = ctx
+    g = np.array(cfg.goal)
+    Q = [np.array(cfg.start), g]
+    for k in range(7):
+        q = g.copy(); q[k] += 4 * DEG; Q.append(q)
+        q = g.copy(); q[k] -= 4 * DEG; Q.append(q)
+    got = _compare_expand(o, s, np.array(Q))
+    assert (got["flags"] & 2).sum() >= 7   # goal successors (short primitive back, or the snap)
+
+
+def test_expand_batch_fork_xy_rotation(small_cfg):
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    o = Oracle(small_cfg, xy_rotate=True)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(small_cfg, xy_rotate=True)
+    o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    _compare_expand(o, s, _random_states(100, 8))
+
+
+def test_getsuccs_ids_match_sequential_reference_order(ctx):
+    cfg, o, s = ctx
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)   # fresh query on both sides
+    assert o.set_start(cfg.start) == s.set_start(cfg.start) == 1
+    frontier = [1]
+    seen = 0
+    for _ in range(40):
+        i = frontier[seen]; seen += 1
+        es, ec = o.get_succs(i)
+        gs, gc = s.get_succs(i)
+        assert np.array_equal(es, gs) and np.array_equal(ec, gc)
+        frontier += [int(x) for x in es if x != 0 and x not in frontier]
+    assert o.num_states() == s.num_states()
+    for i in range(1, s.num_states()):
+        eq, ecd = o.get_state(i)
+        gq, gcd = s.get_state(i)
+        assert np.array_equal(eq, gq) and np.array_equal(ecd, gcd)
+        assert o.heuristic_q(eq) == s.goal_heuristic(i)
+
+
+@pytest.mark.parametrize("goal_kind", ["joint", "xyz"])
+def test_arastar_expansion_order_and_cost(small_cfg, goal_kind):
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = small_cfg
+    o = Oracle(cfg)
+    s = capi.Space.from_config(cfg, batch_states=256)
+    if goal_kind == "joint":
+        o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    else:
+        p = o.planning_fk(cfg.goal)
+        o.set_goal_xyz(p, [0.04] * 3); s.set_goal_xyz(p, [0.04] * 3)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    o.search_params(5.0, 1.0, 1.0, True, True, 6000, 3000)
+    eo = o.plan()
+    go = s.plan(5.0, 1.0, 1.0, True, True, 6000, 3000)
+    assert eo["ok"] == go["solved"]
+    assert eo["expansions"] == go["expansions"]
+    assert np.array_equal(eo["expansion_log"], go["expansion_log"])   # expanded-state set AND order, ids bit-exact
+    assert eo["cost"] == go["cost"]
+    assert np.array_equal(eo["path"], go["path"])
+    assert eo["eps"] == go["satisfied_eps"]
+    assert o.num_states() == s.num_states()
+    assert eo["succ_evals"] == go["committed_succ_evals"]
+    if go["solved"]:
+        q = s.extract_path(go["path"])
+        assert np.array_equal(q[0], np.array(cfg.start))
