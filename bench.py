@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- successor evaluations/s of the ARA* state-expansion hot path on MI355X.
+
+A "step" is one frontier-batched expansion: B = 4096 open states of a real ARA* search on the
+config-2 scene (7-DOF arm, 256^3 voxel grid @ 0.02 m, tabletop + 64 seeded boxes), every motion
+primitive applied to every state (k_state_prep + k_expand), inputs and outputs resident in HBM.
+`value` = successor evaluations (state x active primitive, the loop body of
+smpl/src/graph/manip_lattice.cpp:263-305) per second, whole job.
+
+N > 1 (driver: torch.distributed.run, one rank per GPU, RCCL): the batched-query shard of
+BASELINE config 4 -- every rank owns an independent query (its own goal, BFS grid, state table and
+frontier) on the replicated scene, no collective on the data path; per-rank result records are
+all-gathered at the end.  Weak scaling.
+
+Extra objects on the JSON line: `roofline` (k_expand, HIP events on the launch stream inside the
+timed region), `cpu_baseline` (the oracle, one host thread, rank 0 at N=1) and `planner`
+(states expanded/s of a bounded ARA* query, GPU engine vs oracle, with the parity bits).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--planner-expansions", type=int, default=40000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-planner", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from smpl_amd import capi, scenes
+
+    # ---- inputs: config-2 scene; every rank its own query on the replicated scene ----
+    cfg = scenes.config2(n=args.grid)
+    goal = list(cfg.goal)
+    if rank > 0:   # independent queries: shift the goal by whole lattice cells, keep it reachable
+        shift = [(-3 * rank) % 17 - 8, (2 * rank) % 9 - 4, (5 * rank) % 13 - 6, (-rank) % 7 - 3, 4 * (rank % 5 - 2),
+                 4 * (rank % 3 - 1), 4 * (rank % 7 - 3)]
+        goal = [g + c * scenes.DEG for g, c in zip(goal, shift)]
+    space = capi.Space.from_config(cfg, batch_states=args.batch)
+    ok, _ = space.state_valid_batch(np.array([goal]))
+    if not ok[0]:
+        goal = list(cfg.goal)
+    space.set_goal_joint(goal, cfg.goal_tol)
+    space.set_start(cfg.start)
+    # a real frontier: run the search far enough to own >= B states, take the first B created
+    p = cfg.params
+    warm = space.plan(p.eps0, p.eps_final, p.eps_delta, True, True, 1500, 1500)
+    B = args.batch
+    if space.num_states() <= B:
+        raise SystemExit(f"search produced only {space.num_states()} states, need {B}")
+    Q = np.stack([space.get_state(i)[0] for i in range(1, B + 1)])
+    N, M = space.N, space.M
+
+    dev = torch.device("cuda", local_rank)
+    d_q = torch.from_numpy(Q).to(dev)
+    d_flags = torch.zeros(B * M, dtype=torch.uint8, device=dev)
+    d_coord = torch.zeros(B * M * N, dtype=torch.int32, device=dev)
+    d_sq = torch.zeros(B * M * N, dtype=torch.float64, device=dev)
+    d_h = torch.zeros(B * M, dtype=torch.int32, device=dev)
+    d_cost = torch.zeros(B * M, dtype=torch.int32, device=dev)
+    d_lk = torch.zeros(B * M, dtype=torch.int32, device=dev)
+    d_work = torch.zeros(space.expand_work_bytes(B), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(space.counters_bytes(B) // 8, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        space.expand_batch_device(d_q.data_ptr(), B, d_flags.data_ptr(), d_coord.data_ptr(), d_sq.data_ptr(),
+                                  d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_work.data_ptr(),
+                                  d_cnt.data_ptr(), stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    d_cnt.zero_()
+    space.profile_begin(args.steps)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    prep_ms, expand_ms, launches = space.profile_end()
+    evals, valid, lookups_ref, lookups_done, configs, state_lookups = space.counters_read(d_cnt.data_ptr(), B)
+    elapsed = t1 - t0
+
+    # ---- whole-job aggregate: max time over ranks, sum of units ----
+    rec = torch.tensor([float(evals), elapsed, float(valid)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)   # RCCL all-gather of the per-rank result records
+        allrec = torch.stack(allrec).cpu().numpy()
+    else:
+        allrec = rec.cpu().numpy()[None]
+    total_evals = float(allrec[:, 0].sum())
+    tmax = float(allrec[:, 1].max())
+    value = total_evals / tmax
+
+    # ---- roofline of the dominant kernel (k_pipe_configs: the collision check), this rank ----
+    # SURVEY 8(d), collision kernel: algorithmic bytes = 4 B per distance-grid lookup + 8N B per configuration.
+    # HIP events on the launch stream bracket the kernel inside the timed region (smplx_profile_*).
+    L_ = max(launches, 1)
+    cfg_per_launch = configs / L_
+    lk_per_launch = (lookups_done + state_lookups) / L_
+    alg_bytes = 4.0 * lk_per_launch + 8.0 * N * cfg_per_launch
+    k_ms = prep_ms / L_            # first event interval = k_pipe_configs
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None, "kernel": "k_pipe_configs",
+                "kernel_ms": round(k_ms, 4), "finish_kernel_ms": round(expand_ms / L_, 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes), "configs_per_launch": int(cfg_per_launch),
+                "lookups_per_launch": int(lk_per_launch), "evals_per_launch": int(evals / L_),
+                "succ_eval_bytes_per_launch": int(evals / L_ * (20 * N + 8) + 4.0 * lookups_ref / L_),
+                "reference_lookups_per_launch": int(lookups_ref / L_)}
+
+    out = {
+        "metric": "successor evaluations/sec, ManipLattice GetSuccs loop body (7-DOF arm, 256^3 voxel grid)",
+        "value": round(value, 1), "unit": "successor evaluations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg2: 7-DOF arm7, {args.grid}^3 grid @ 0.02 m, tabletop + 64 boxes (seed 2), "
+                               f"frontier batch B={B} open states x M={M} primitives, eps 5 ARA* frontier",
+                   "batch_states": B, "primitives": M, "grid": args.grid, "queries": world,
+                   "parallelism": f"query-shard x{world}" if world > 1 else "single query"},
+        "valid_fraction": round(valid / max(evals, 1), 4),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_binding import Oracle
+        o = Oracle(cfg)
+        o.set_goal_joint(goal, cfg.goal_tol)
+        r = o.eval_batch_timed(Q, args.cpu_seconds)
+        cpu_rate = r["evals"] / r["seconds"]
+        out["cpu_baseline"] = {"value": round(cpu_rate, 1), "unit": "successor evaluations/s", "cores": 1, "kind": "port",
+                               "sample": f"{r['passes']} pass(es) over the same {B}-state frontier batch "
+                                         f"({r['evals']} evaluations, {r['seconds']:.1f} s), oracle/ C++ -O2, 1 thread, "
+                                         f"logging/visualisation off, 4-byte cells; host has {os.cpu_count()} cores"}
+        if not args.no_planner:
+            nb = args.planner_expansions
+            o2 = Oracle(cfg)
+            o2.set_goal_joint(goal, cfg.goal_tol)
+            o2.set_start(cfg.start)
+            o2.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+            ro = o2.plan()
+            sp2 = capi.Space.from_config(cfg, batch_states=args.batch)
+            sp2.set_goal_joint(goal, cfg.goal_tol)
+            sp2.set_start(cfg.start)
+            rg = sp2.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+            out["planner"] = {
+                "query": "cfg2 single query, ARA* eps 5->1 step 1, expansion bound %d" % nb,
+                "gpu_states_expanded_per_s": round(rg["expansions"] / rg["seconds"], 1),
+                "cpu_states_expanded_per_s": round(ro["expansions"] / ro["seconds"], 1),
+                "expansions": rg["expansions"], "path_cost": rg["cost"], "satisfied_eps": rg["satisfied_eps"],
+                "gpu_seconds": round(rg["seconds"], 4), "cpu_seconds": round(ro["seconds"], 4),
+                "gpu_succ_evals_total": rg["gpu_succ_evals"], "committed_succ_evals": rg["committed_succ_evals"],
+                "speculative_succ_evals": rg["gpu_succ_evals"] - rg["committed_succ_evals"],
+                "gpu_batches": rg["gpu_batches"], "cache_hits": rg["cache_hits"], "cache_misses": rg["cache_misses"],
+                "parity": {"cost_equal": bool(ro["cost"] == rg["cost"]),
+                           "expansions_equal": bool(ro["expansions"] == rg["expansions"]),
+                           "expanded_ids_equal": bool(np.array_equal(ro["expansion_log"], rg["expansion_log"])),
+                           "path_equal": bool(np.array_equal(ro["path"], rg["path"]))}}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

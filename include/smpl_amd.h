@@ -80,7 +80,9 @@ typedef struct smplx_params {
     int32_t use_long_and_short;
     double padding;                   /* SelfCollisionModel m_padding, default 0 */
     int32_t batch_states;             /* frontier batch B (0 = default 4096) */
-    int32_t reserved;
+    int32_t reserved;                 /* bit 0: fused mode -- one GPU thread walks a whole edge in the
+                                         reference's waypoint order (exact reference lookup tallies);
+                                         default 0: waypoint-parallel pipeline (same results, faster) */
 } smplx_params;
 
 /* RobotPlanningSpace::init + insertHeuristic (smpl/include/smpl/graph/robot_planning_space.h:68,89;
@@ -127,12 +129,24 @@ int smplx_bfs_levels(const smplx_space* s);
 int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q,
                        int32_t* h, int32_t* cost, int32_t* lookups);
 /* same, everything resident in HBM; launches on `stream` and returns without synchronising.
- * work: device scratch of smplx_expand_work_bytes(s, B) bytes.  counters (3 x uint64, may be NULL):
- * successor evaluations, valid successors, grid lookups -- accumulated. */
+ * work: device scratch of smplx_expand_work_bytes(s, B) bytes.  d_counters: see smplx_counters_bytes (may be NULL). */
 size_t smplx_expand_work_bytes(const smplx_space* s, int B);
+/* d_counters: device scratch of smplx_counters_bytes(s, B) bytes, zeroed by the caller; tallies accumulate per
+ * thread block without atomics.  smplx_counters_read sums them (synchronous copy): out[0] successor evaluations,
+ * out[1] valid successors, out[2] grid lookups the reference algorithm makes for those edges, out[3] grid lookups
+ * the edge kernels themselves issued (waypoint 0 is checked once per state), out[4] configurations checked by
+ * k_pipe_configs (states + waypoints; 0 in fused mode), out[5] lookups of the per-state checks among them. */
+size_t smplx_counters_bytes(const smplx_space* s, int B);
+int smplx_counters_read(const smplx_space* s, const uint64_t* d_counters, int B, uint64_t out[6]);
 int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord,
                               double* d_succ_q, int32_t* d_h, int32_t* d_cost, int32_t* d_lookups,
                               void* d_work, uint64_t* d_counters, void* stream);
+
+/* per-kernel timing of the next max_launches expand launches with HIP events recorded on the launch
+ * stream (no synchronisation until _end): summed milliseconds of k_state_prep and k_expand.
+ * Mirrors the ARAStar/ManipLattice stopwatch hooks (smpl/src/profiling.h:56-117). */
+int smplx_profile_begin(smplx_space* s, int max_launches);
+int smplx_profile_end(smplx_space* s, double* prep_ms, double* expand_ms, int* launches);
 
 /* ManipLattice::setStart (manip_lattice.cpp:1944-1981): limits + collision check, id assigned */
 int smplx_set_start(smplx_space* s, const double* q, int* id);

@@ -314,6 +314,42 @@ void orc_eval_state(void* h, const double* q, unsigned char* flags, int* coord, 
     L.expansions = ex;
 }
 
+// CPU baseline: the GetSuccs loop body over a batch of parent states, repeated until at least
+// min_seconds of work has been done.  Returns evaluations (state x active primitive) and seconds.
+void orc_eval_batch_timed(void* h, const double* Q, int B, double min_seconds, long* evals, long* valid, double* seconds,
+                          int* passes)
+{
+    Ctx* c = (Ctx*)h;
+    ManipLattice& L = c->lattice;
+    const int N = c->robot.jointVariableCount();
+    const long ev0 = L.succ_evals;
+    long nvalid = 0;
+    int np = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    double el = 0.0;
+    do {
+        for (int i = 0; i < B; ++i) {
+            const size_t before = L.state_coords.size();
+            const int tmp = L.reserveHashEntry();
+            L.state_angles[tmp].assign(Q + (size_t)i * N, Q + (size_t)(i + 1) * N);
+            std::vector<int> s, k;
+            L.GetSuccs(tmp, &s, &k);
+            nvalid += (long)s.size();
+            for (size_t id = before; id < L.state_coords.size(); ++id)
+                if (!L.state_coords[id].empty()) L.state_to_id.erase(L.state_coords[id]);
+            L.state_coords.resize(before);
+            L.state_angles.resize(before);
+        }
+        ++np;
+        el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (el < min_seconds);
+    *evals = L.succ_evals - ev0;
+    *valid = nvalid;
+    *seconds = el;
+    *passes = np;
+    L.succ_evals = ev0;
+}
+
 // --- search ---
 void orc_search_params(void* h, double eps0, double eps_final, double eps_delta, int improve, int bounded,
                        int max_exp_init, int max_exp)

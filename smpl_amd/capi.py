@@ -28,7 +28,8 @@ SYMBOLS = [
     "smplx_heuristic_batch", "smplx_bfs_size", "smplx_bfs_copy", "smplx_bfs_levels", "smplx_expand_batch",
     "smplx_expand_work_bytes", "smplx_expand_batch_device", "smplx_set_start", "smplx_start_id", "smplx_goal_id",
     "smplx_get_succs", "smplx_hint_frontier", "smplx_get_goal_heuristic", "smplx_num_states", "smplx_get_state",
-    "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path",
+    "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_profile_begin",
+    "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read",
 ]
 
 
@@ -75,6 +76,9 @@ def lib():
             getattr(L, name).restype = None
         L.smplx_expand_batch_device.argtypes = [C.c_void_p] + [C.c_void_p, C.c_int] + [C.c_void_p] * 9
         L.smplx_expand_work_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.smplx_counters_bytes.restype = C.c_size_t
+        L.smplx_counters_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.smplx_counters_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _u64p]
         _lib = L
     return _lib
 
@@ -158,7 +162,7 @@ class Model:
 class Space:
     """ManipLattice + BfsHeuristic + CollisionSpace for one query, on one GPU."""
 
-    def __init__(self, model: Model, grid: Grid, mprim_text: str, params, batch_states: int = 0):
+    def __init__(self, model: Model, grid: Grid, mprim_text: str, params, batch_states: int = 0, fused: bool = False):
         self.model, self.grid = model, grid
         P = Params()
         for i, r in enumerate(params.resolutions):
@@ -173,13 +177,14 @@ class Space:
         P.use_long_and_short = int(params.use_long_and_short)
         P.padding = 0.0
         P.batch_states = batch_states
+        P.reserved = 1 if fused else 0
         self.h = C.c_void_p()
         _chk(lib().smplx_space_create(model.h, grid.h, mprim_text.encode(), C.byref(P), C.byref(self.h)))
         self.N = lib().smplx_space_num_vars(self.h)
         self.M = lib().smplx_space_num_prims(self.h)
 
     @classmethod
-    def from_config(cls, cfg, batch_states: int = 0, xy_rotate=None):
+    def from_config(cls, cfg, batch_states: int = 0, xy_rotate=None, fused: bool = False):
         g = Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
         m = Model(cfg.robot_text)
         p = cfg.params
@@ -187,7 +192,7 @@ class Space:
             import copy
             p = copy.copy(p)
             p.xy_rotate_by_var3 = xy_rotate
-        return cls(m, g, cfg.mprim, p, batch_states)
+        return cls(m, g, cfg.mprim, p, batch_states, fused)
 
     def close(self):
         if self.h:
@@ -271,10 +276,26 @@ class Space:
     def expand_work_bytes(self, B):
         return lib().smplx_expand_work_bytes(self.h, B)
 
+    def counters_bytes(self, B):
+        return lib().smplx_counters_bytes(self.h, B)
+
+    def counters_read(self, d_counters, B):
+        out = np.zeros(6, np.uint64)
+        _chk(lib().smplx_counters_read(self.h, d_counters, B, _p(out, _u64p)))
+        return [int(x) for x in out]
+
     def expand_batch_device(self, d_q, B, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, d_work, d_counters, stream):
         """All arguments are raw device pointers (ints); launches on `stream`, does not synchronise."""
         _chk(lib().smplx_expand_batch_device(self.h, d_q, B, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, d_work,
                                              d_counters, stream))
+
+    def profile_begin(self, max_launches):
+        _chk(lib().smplx_profile_begin(self.h, max_launches))
+
+    def profile_end(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        _chk(lib().smplx_profile_end(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def set_start(self, q):
         q = _f64(q); i = C.c_int()

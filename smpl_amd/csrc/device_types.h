@@ -26,7 +26,8 @@ enum { SMPLX_MP_LONG = -1, SMPLX_MP_SNAP_RPY = 0, SMPLX_MP_SNAP_XYZ = 1, SMPLX_M
 // goal types (smpl/include/smpl/types.h)
 enum { SMPLX_GOAL_XYZ = 0, SMPLX_GOAL_XYZ_RPY = 1, SMPLX_GOAL_JOINT = 2 };
 // per-successor flags
-enum { SMPLX_F_VALID = 1, SMPLX_F_GOAL = 2, SMPLX_F_INACTIVE = 0x10, SMPLX_F_LIMITS = 0x20, SMPLX_F_COLLISION = 0x40 };
+enum { SMPLX_F_VALID = 1, SMPLX_F_GOAL = 2, SMPLX_F_INACTIVE = 0x10, SMPLX_F_LIMITS = 0x20, SMPLX_F_COLLISION = 0x40,
+       SMPLX_F_DEFERRED = 0x80 /* internal: edge did not fit the work list, resolved by a fused pass */ };
 
 struct SmplxJoint {          // depth-first pre-order; the child link of joint i is "link i"
     double origin[12];       // row-major 3x4
@@ -47,7 +48,7 @@ struct SmplxNode {           // sphere-tree node; trees are stored post-order, r
     int32_t pad;
 };
 
-struct SmplxModelDev {
+struct alignas(16) SmplxModelDev {
     int32_t njoints, nvars, ntrees, nnodes, npairs, nslots, nchain, pad0;
     SmplxJoint joints[SMPLX_MAX_JOINTS];
     SmplxNode nodes[SMPLX_MAX_NODES];
@@ -95,6 +96,9 @@ struct SmplxGoalDev {
     double xyz[3];
     double xyz_tol[3];
 };
+
+static_assert(sizeof(SmplxModelDev) % 16 == 0 && sizeof(SmplxJoint) % 16 == 0 && sizeof(SmplxNode) % 16 == 0,
+              "the model is copied to LDS in 16-byte pieces");
 
 // everything one query needs, resident in HBM
 struct SmplxSpaceDev {

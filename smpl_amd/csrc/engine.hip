@@ -160,9 +160,10 @@ struct smplx_space {
     bool goal_set = false;
     double goal_xyz[3] = {0, 0, 0};
     // scratch
-    DevBuf<double> b_q, b_q2, b_goal_dist, b_sq, b_xyz;
-    DevBuf<unsigned char> b_pvalid, b_flags;
-    DevBuf<int32_t> b_plook, b_coord, b_h, b_cost, b_lookups, b_way;
+    DevBuf<double> b_q, b_q2, b_sq, b_xyz;
+    DevBuf<unsigned char> b_flags, b_work;
+    DevBuf<int32_t> b_coord, b_h, b_cost, b_lookups, b_way;
+    bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
     DevBuf<unsigned long long> b_counters;
     PinBuf<double> p_q, p_sq;
     PinBuf<unsigned char> p_flags;
@@ -189,6 +190,9 @@ struct smplx_space {
     int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0;
     std::vector<int32_t> eval_count;    // per id: evaluated (active) primitives, for committed_evals
     std::vector<int32_t> expansion_log;
+    // optional per-kernel timing of expand launches (bench.py roofline): 3 events per launch
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -284,15 +288,91 @@ int run_bfs(smplx_space* s, const double xyz[3])
     return SMPLX_OK;
 }
 
-int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
-                  int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, double* d_goal_dist, unsigned char* d_pvalid,
-                  int32_t* d_plook, unsigned long long* d_counters, hipStream_t stream)
+// per-block tallies: 4 uint64 per block of the (state x primitive) grid (kernels.hip tally_block)
+inline size_t counter_words(int B, int M) { return (size_t)blocks_for((long long)B * M, SMPLX_BLOCK) * SMPLX_TALLIES; }
+
+// carve of the per-batch device scratch (smplx_expand_work_bytes)
+struct ExpandWork {
+    double* goal_dist;
+    int32_t* state_lookups;
+    unsigned char* state_bad;
+    int32_t* edge_w;
+    int32_t* edge_lookups;
+    unsigned char* edge_bad;
+    int32_t* work_count;
+    unsigned int* work;
+    int capacity;
+};
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+size_t expand_work_bytes(int B, int M)
 {
-    hipLaunchKernelGGL(k_state_prep, dim3(blocks_for(B, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space,
-                       d_q, (const int64_t*)nullptr, B, d_goal_dist, d_pvalid, d_plook);
-    hipLaunchKernelGGL(k_expand, dim3(blocks_for((long long)B * s->M, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, stream,
-                       s->d_space, d_q, (const int64_t*)nullptr, B, d_goal_dist, d_pvalid, d_plook, d_flags, d_coord, d_sq,
-                       d_h, d_cost, d_lookups, d_counters);
+    const size_t b = (size_t)B, bm = (size_t)B * M;
+    return align256(b * 8) + align256(b * 4) + align256(b) + align256(bm * 4) + align256(bm * 4) + align256(bm) + 2048 +
+           align256(bm * 16 * 4);
+}
+
+ExpandWork carve_work(void* base, int B, int M)
+{
+    unsigned char* w = (unsigned char*)base;
+    const size_t b = (size_t)B, bm = (size_t)B * M;
+    ExpandWork k;
+    k.goal_dist = (double*)w; w += align256(b * 8);
+    k.state_lookups = (int32_t*)w; w += align256(b * 4);
+    k.state_bad = w; w += align256(b);
+    k.edge_w = (int32_t*)w; w += align256(bm * 4);
+    k.edge_lookups = (int32_t*)w; w += align256(bm * 4);
+    k.edge_bad = w; w += align256(bm);
+    k.work_count = (int32_t*)w; w += 2048;   // 8 shard counters + deferred count, one 128-byte line each
+    k.work = (unsigned int*)w;
+    k.capacity = (int)std::min<size_t>(bm * 16, (size_t)1 << 30) / 8 * 8;
+    return k;
+}
+
+int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
+                  int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
+                  hipStream_t stream)
+{
+    const ExpandWork k = carve_work(d_work, B, s->M);
+    hipEvent_t* ev = nullptr;
+    if (s->prof_used + 3 <= s->prof_events.size()) { ev = &s->prof_events[s->prof_used]; s->prof_used += 3; }
+    const int bs = blocks_for(B, SMPLX_BLOCK);
+    const int be = blocks_for((long long)B * s->M, SMPLX_BLOCK);
+    const int64_t* norefs = nullptr;
+    if (s->fused_mode) {
+        // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
+        if (ev) (void)hipEventRecord(ev[0], stream);
+        hipLaunchKernelGGL(k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+                           k.goal_dist, k.state_bad, k.state_lookups);
+        if (ev) (void)hipEventRecord(ev[1], stream);
+        hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+                           k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
+                           d_counters, (const int*)nullptr);
+        if (ev) (void)hipEventRecord(ev[2], stream);
+    } else {
+        const size_t lm = smplx_lds_model_bytes();
+        hipLaunchKernelGGL(k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+                           k.goal_dist, k.work_count);
+        hipLaunchKernelGGL(k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+                           k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
+                           k.work, k.work_count, k.capacity);
+        if (ev) (void)hipEventRecord(ev[0], stream);
+        const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK);
+        hipLaunchKernelGGL(k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+                           d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, k.work, k.work_count,
+                           k.capacity);
+        if (ev) (void)hipEventRecord(ev[1], stream);
+        hipLaunchKernelGGL(k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+                           k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, d_flags, d_coord, d_sq, d_h,
+                           d_cost, d_lookups, d_counters);
+        if (ev) (void)hipEventRecord(ev[2], stream);
+        // edges whose waypoints did not fit the work list (work_count[1] of them; normally none): every block of
+        // this pass returns at once when the count is zero
+        hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+                           k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
+                           d_counters, (const int*)(k.work_count + 8 * 32));
+    }
     HIP_TRY(hipGetLastError());
     return SMPLX_OK;
 }
@@ -302,16 +382,14 @@ int reserve_expand(smplx_space* s, int B)
     const size_t BM = (size_t)B * s->M;
     int e;
     if ((e = s->b_q.reserve((size_t)B * s->N))) return e;
-    if ((e = s->b_goal_dist.reserve(B))) return e;
-    if ((e = s->b_pvalid.reserve(B))) return e;
-    if ((e = s->b_plook.reserve(B))) return e;
+    if ((e = s->b_work.reserve(expand_work_bytes(B, s->M)))) return e;
     if ((e = s->b_flags.reserve(BM))) return e;
     if ((e = s->b_coord.reserve(BM * s->N))) return e;
     if ((e = s->b_sq.reserve(BM * s->N))) return e;
     if ((e = s->b_h.reserve(BM))) return e;
     if ((e = s->b_cost.reserve(BM))) return e;
     if ((e = s->b_lookups.reserve(BM))) return e;
-    if ((e = s->b_counters.reserve(4))) return e;
+    if ((e = s->b_counters.reserve(counter_words(B, s->M)))) return e;
     return SMPLX_OK;
 }
 
@@ -376,7 +454,7 @@ int run_batch(smplx_space* s, int id)
     for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
     HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * B * N, hipMemcpyHostToDevice, s->stream));
     if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
-                           s->b_goal_dist.p, s->b_pvalid.p, s->b_plook.p, s->b_counters.p, s->stream))) return e;
+                           s->b_work.p, s->b_counters.p, s->stream))) return e;
     HIP_TRY(hipMemcpyAsync(s->p_flags.p, s->b_flags.p, BM, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(s->p_h.p, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(s->p_coord.p, s->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost, s->stream));
@@ -568,6 +646,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->model = model->hm;
     s->grid = grid;
     s->params = *params;
+    s->fused_mode = (params->reserved & 1) != 0;
     s->N = s->model.dev.nvars;
     if (!smplx::load_mprim_text(mprim_text, params->resolutions, s->N, s->actions)) {
         const std::string err = s->actions.error;
@@ -628,6 +707,7 @@ void smplx_space_destroy(smplx_space* s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
     if (s->d_space) (void)hipFree(s->d_space);
     if (s->d_bfs) (void)hipFree(s->d_bfs);
     if (s->d_queue[0]) (void)hipFree(s->d_queue[0]);
@@ -811,7 +891,7 @@ int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, i
     HIP_TRY(hipMemsetAsync(s->b_sq.p, 0, sizeof(double) * BM * s->N, s->stream));
     HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * B * s->N, hipMemcpyHostToDevice, s->stream));
     if (int e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
-                              s->b_goal_dist.p, s->b_pvalid.p, s->b_plook.p, nullptr, s->stream)) return e;
+                              s->b_work.p, nullptr, s->stream)) return e;
     if (flags) HIP_TRY(hipMemcpyAsync(flags, s->b_flags.p, BM, hipMemcpyDeviceToHost, s->stream));
     if (coord) HIP_TRY(hipMemcpyAsync(coord, s->b_coord.p, sizeof(int32_t) * BM * s->N, hipMemcpyDeviceToHost, s->stream));
     if (succ_q) HIP_TRY(hipMemcpyAsync(succ_q, s->b_sq.p, sizeof(double) * BM * s->N, hipMemcpyDeviceToHost, s->stream));
@@ -824,10 +904,8 @@ int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, i
 
 size_t smplx_expand_work_bytes(const smplx_space* s, int B)
 {
-    (void)s;
-    // goal_dist (8) + parent_lookups (4) + parent_valid (1) per state, each 256-B aligned
-    const size_t b = (size_t)B;
-    return ((b * 8 + 255) / 256 + (b * 4 + 255) / 256 + (b + 255) / 256) * 256;
+    if (!s || B <= 0) return 0;
+    return expand_work_bytes(B, s->M);
 }
 
 int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord, double* d_succ_q,
@@ -836,13 +914,59 @@ int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t*
     if (!s || !d_q || !d_flags || !d_coord || !d_succ_q || !d_h || !d_cost || !d_lookups || !d_work || B <= 0)
         return set_error(SMPLX_E_ARG, "bad argument");
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first");
-    unsigned char* w = (unsigned char*)d_work;
-    const size_t b = (size_t)B;
-    double* gd = (double*)w;
-    int32_t* pl = (int32_t*)(w + ((b * 8 + 255) / 256) * 256);
-    unsigned char* pv = w + ((b * 8 + 255) / 256 + (b * 4 + 255) / 256) * 256;
-    return launch_expand(s, d_q, B, d_flags, d_coord, d_succ_q, d_h, d_cost, d_lookups, gd, pv, pl,
+    return launch_expand(s, d_q, B, d_flags, d_coord, d_succ_q, d_h, d_cost, d_lookups, d_work,
                          (unsigned long long*)d_counters, (hipStream_t)stream);
+}
+
+size_t smplx_counters_bytes(const smplx_space* s, int B)
+{
+    if (!s || B <= 0) return 0;
+    return counter_words(B, s->M) * sizeof(unsigned long long);
+}
+
+int smplx_counters_read(const smplx_space* s, const uint64_t* d_counters, int B, uint64_t out[6])
+{
+    if (!s || !d_counters || !out || B <= 0) return set_error(SMPLX_E_ARG, "bad argument");
+    const size_t cw = counter_words(B, s->M);
+    std::vector<unsigned long long> part(cw);
+    HIP_TRY(hipMemcpy(part.data(), d_counters, sizeof(unsigned long long) * cw, hipMemcpyDeviceToHost));
+    for (int k = 0; k < SMPLX_TALLIES; ++k) out[k] = 0;
+    for (size_t i = 0; i < cw; ++i) out[i % SMPLX_TALLIES] += part[i];
+    return SMPLX_OK;
+}
+
+int smplx_profile_begin(smplx_space* s, int max_launches)
+{
+    if (!s || max_launches < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
+    s->prof_events.clear();
+    s->prof_used = 0;
+    for (int i = 0; i < 3 * max_launches; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->prof_events.push_back(e);
+    }
+    return SMPLX_OK;
+}
+
+int smplx_profile_end(smplx_space* s, double* prep_ms, double* expand_ms, int* launches)
+{
+    if (!s || !prep_ms || !expand_ms || !launches) return set_error(SMPLX_E_ARG, "null argument");
+    double a = 0.0, b = 0.0;
+    const int n = (int)(s->prof_used / 3);
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventSynchronize(s->prof_events[3 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&t, s->prof_events[3 * i], s->prof_events[3 * i + 1]));
+        a += t;
+        HIP_TRY(hipEventElapsedTime(&t, s->prof_events[3 * i + 1], s->prof_events[3 * i + 2]));
+        b += t;
+    }
+    *prep_ms = a; *expand_ms = b; *launches = n;
+    for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
+    s->prof_events.clear();
+    s->prof_used = 0;
+    return SMPLX_OK;
 }
 
 int smplx_set_start(smplx_space* s, const double* q, int* id)
@@ -1136,8 +1260,10 @@ int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, 
     S.start_id = s->start_id;
     S.goal_id = 0;
     s->expansion_log.clear();
-    if (int e = s->b_counters.reserve(4)) return e;
-    HIP_TRY(hipMemsetAsync(s->b_counters.p, 0, sizeof(unsigned long long) * 4, s->stream));
+    const int capB = s->params.batch_states > 0 ? s->params.batch_states : 4096;
+    const size_t cw = counter_words(capB, s->M);
+    if (int e = s->b_counters.reserve(cw)) return e;
+    HIP_TRY(hipMemsetAsync(s->b_counters.p, 0, sizeof(unsigned long long) * cw, s->stream));
     const int64_t b0 = s->gpu_batches, h0 = s->cache_hits, m0 = s->cache_misses, c0 = s->committed_evals;
     std::vector<int> sol;
     int cost = 0;
@@ -1146,7 +1272,11 @@ int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, 
     const auto t1 = std::chrono::steady_clock::now();
     if (S.error) return S.error;
     unsigned long long counters[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(counters, s->b_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
+    {
+        std::vector<unsigned long long> part(cw);
+        HIP_TRY(hipMemcpy(part.data(), s->b_counters.p, sizeof(unsigned long long) * cw, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cw; ++i) if (i % SMPLX_TALLIES < 4) counters[i % SMPLX_TALLIES] += part[i];
+    }
     std::memset(stats, 0, sizeof(*stats));
     stats->solved = ok;
     stats->path_len = (int)sol.size();

@@ -7,12 +7,15 @@
 #include "device_types.h"
 
 #define SMPLX_BLOCK 128          // 2 waves; per-thread LDS scratch keeps ~4 blocks per CU resident
-#define SMPLX_STACK_BYTES 32     // per-thread DFS stack (node indices, one byte each)
+#define SMPLX_STACK_BYTES 32
+#define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
 // dynamic LDS bytes a collision kernel needs for a model
+static inline size_t smplx_lds_model_bytes(void) { return sizeof(SmplxModelDev); }
 static inline size_t smplx_lds_bytes(int nnodes, int ntrees, int nslots)
 {
-    return (size_t)nnodes * sizeof(SmplxNode) + (size_t)(3 * ntrees + 12 * nslots) * 8 * SMPLX_BLOCK +
+    (void)nnodes;
+    return sizeof(SmplxModelDev) + (size_t)(3 * ntrees + 12 * nslots) * 8 * SMPLX_BLOCK +
            (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
 }
 
@@ -22,7 +25,20 @@ __global__ void k_state_prep(const SmplxSpaceDev* S, const double* Q, const int6
 __global__ void k_expand(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
                          const unsigned char* parent_valid, const int* parent_lookups, unsigned char* out_flags,
                          int* out_coord, double* out_q, int* out_h, int* out_cost, int* out_lookups,
-                         unsigned long long* counters);
+                         unsigned long long* counters, const int* deferred_count);
+__global__ void k_pipe_prep(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist,
+                            int* work_count);
+__global__ void k_pipe_setup(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
+                             unsigned char* out_flags, double* out_q, int* edge_w, int* edge_lookups,
+                             unsigned char* edge_bad, int* state_lookups, unsigned char* state_bad, unsigned int* work,
+                             int* work_count, int capacity);
+__global__ void k_pipe_configs(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* out_q,
+                               const int* edge_w, int* edge_lookups, unsigned char* edge_bad, int* state_lookups,
+                               unsigned char* state_bad, const unsigned int* work, const int* work_count, int capacity);
+__global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const int* edge_w,
+                              const int* edge_lookups, const unsigned char* edge_bad, const int* state_lookups,
+                              const unsigned char* state_bad, unsigned char* out_flags, int* out_coord, double* out_q,
+                              int* out_h, int* out_cost, int* out_lookups, unsigned long long* counters);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

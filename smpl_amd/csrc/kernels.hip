@@ -456,24 +456,68 @@ __device__ __forceinline__ int var_to_coord(const SmplxModelDev* __restrict__ M,
     return (int)(((x - M->var_min[v]) / delta) + 0.5);
 }
 
-__device__ __forceinline__ ThreadLds setup_lds(const SmplxModelDev* __restrict__ M, unsigned char* smem)
+// Cooperative copy of the USED part of the compiled model into LDS (header + joints, sphere-tree
+// nodes, the small per-tree / per-pair / per-variable tables) in 16-byte pieces, all loads of a
+// thread issued before the first store.  Every later read of the model is a uniform-address LDS
+// broadcast instead of a dependent global load.
+__device__ __forceinline__ const SmplxModelDev* stage_model(const SmplxModelDev* __restrict__ Mg, unsigned char* smem)
+{
+    typedef double __attribute__((ext_vector_type(2))) d2_t;
+    const d2_t* src = reinterpret_cast<const d2_t*>(Mg);
+    d2_t* dst = reinterpret_cast<d2_t*>(smem);
+    const int nj = Mg->njoints, nn = Mg->nnodes;
+    const int seg0 = (int)((offsetof(SmplxModelDev, joints) + (size_t)nj * sizeof(SmplxJoint)) / 16);
+    const int off1 = (int)(offsetof(SmplxModelDev, nodes) / 16);
+    const int seg1 = (int)((size_t)nn * sizeof(SmplxNode) / 16);
+    const int off2 = (int)(offsetof(SmplxModelDev, tree_first) / 16);
+    const int seg2 = (int)(sizeof(SmplxModelDev) / 16) - off2;
+    const int total = seg0 + seg1 + seg2;
+    d2_t v[4];
+    int idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + k * BLOCK;
+        int j = -1;
+        if (i < seg0) j = i;
+        else if (i < seg0 + seg1) j = off1 + (i - seg0);
+        else if (i < total) j = off2 + (i - seg0 - seg1);
+        idx[k] = j;
+        if (j >= 0) v[k] = src[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (idx[k] >= 0) dst[idx[k]] = v[k];
+    for (int i = threadIdx.x + 4 * BLOCK; i < total; i += BLOCK) {   // models larger than 8 KB
+        int j;
+        if (i < seg0) j = i;
+        else if (i < seg0 + seg1) j = off1 + (i - seg0);
+        else j = off2 + (i - seg0 - seg1);
+        dst[j] = src[j];
+    }
+    return reinterpret_cast<const SmplxModelDev*>(smem);
+}
+
+__device__ __forceinline__ ThreadLds setup_lds(const SmplxModelDev* __restrict__ Mg, unsigned char* smem,
+                                               const SmplxModelDev** M_lds)
 {
     ThreadLds L;
-    SmplxNode* nodes = reinterpret_cast<SmplxNode*>(smem);
-    const int nn = M->nnodes;
-    // cooperative copy of the sphere trees (48 B per node) into LDS
-    const int words = nn * (int)(sizeof(SmplxNode) / 8);
-    const double* src = reinterpret_cast<const double*>(M->nodes);
-    double* dst = reinterpret_cast<double*>(nodes);
-    for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
-    L.nodes = nodes;
-    L.d = reinterpret_cast<double*>(smem + (size_t)nn * sizeof(SmplxNode));
+    const SmplxModelDev* Ml = stage_model(Mg, smem);
+    *M_lds = Ml;
+    L.nodes = Ml->nodes;
+    L.d = reinterpret_cast<double*>(smem + sizeof(SmplxModelDev));
     L.root_base = 0;
-    L.slot_base = 3 * M->ntrees;
-    const int nd = 3 * M->ntrees + 12 * M->nslots;
+    L.slot_base = 3 * Mg->ntrees;
+    const int nd = 3 * Mg->ntrees + 12 * Mg->nslots;
     L.stk = reinterpret_cast<unsigned char*>(L.d + (size_t)nd * BLOCK);
     __syncthreads();
     return L;
+}
+
+// kernels that only need the model (no per-thread scratch)
+__device__ __forceinline__ const SmplxModelDev* setup_model_only(const SmplxModelDev* __restrict__ Mg, unsigned char* smem)
+{
+    const SmplxModelDev* Ml = stage_model(Mg, smem);
+    __syncthreads();
+    return Ml;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,8 +529,10 @@ k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
              double* __restrict__ goal_dist, unsigned char* __restrict__ parent_valid, int* __restrict__ parent_lookups)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = &S->model;
-    ThreadLds L = setup_lds(M, smem);
+    const SmplxModelDev* M;
+    ThreadLds L = setup_lds(&S->model, smem, &M);
+    const SmplxGridDev grid = S->grid;
+    const SmplxBfsDev bfs = S->bfs;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= B) return;
     const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
@@ -494,17 +540,39 @@ k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
     planning_fk(M, q, p);
     // BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138)
     int c[3];
-    world_to_cell(S->grid, p, c);
+    world_to_cell(grid, p, c);
     double gd;
-    if (!bfs_in_bounds(S->bfs, c)) gd = (double)0x7FFFFFFF * S->grid.res;
-    else gd = (double)bfs_dist(S->bfs, c) * S->grid.res;
+    if (!bfs_in_bounds(bfs, c)) gd = (double)0x7FFFFFFF * grid.res;
+    else gd = (double)bfs_dist(bfs, c) * grid.res;
     goal_dist[i] = gd;
     EdgeRef e;
     e.start = q; e.finish = q; e.alpha = 0.0;
     int lk = 0;
-    const bool ok = config_valid(M, L, S->grid, e, lk);
+    const bool ok = config_valid(M, L, grid, e, lk);
     parent_valid[i] = ok ? 1 : 0;
     parent_lookups[i] = lk;
+}
+
+// per-block tallies without atomics: block b owns counters[4*b .. 4*b+3] (launches on one stream serialise,
+// so a plain read-modify-write is safe); the host sums the blocks (smplx_counters_read)
+__device__ __forceinline__ void tally_block(unsigned long long* __restrict__ counters, int ev, int va, int lk, int pf,
+                                            int cfgs, int slk)
+{
+    __shared__ int t_acc[BLOCK / 64][SMPLX_TALLIES];
+    const int wv = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) {
+        lk += __shfl_down(lk, off); pf += __shfl_down(pf, off); cfgs += __shfl_down(cfgs, off); slk += __shfl_down(slk, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        t_acc[wv][0] = ev; t_acc[wv][1] = va; t_acc[wv][2] = lk; t_acc[wv][3] = pf; t_acc[wv][4] = cfgs; t_acc[wv][5] = slk;
+    }
+    __syncthreads();
+    if (threadIdx.x < SMPLX_TALLIES) {
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < BLOCK / 64; ++k) v += t_acc[k][threadIdx.x];
+        counters[(size_t)blockIdx.x * SMPLX_TALLIES + threadIdx.x] += (unsigned long long)v;
+    }
 }
 
 // manip_lattice_action_space.cpp:662-691
@@ -528,17 +596,25 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
          const int* __restrict__ parent_lookups,
          unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
          int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
-         unsigned long long* __restrict__ counters)
+         unsigned long long* __restrict__ counters, const int* __restrict__ deferred_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = &S->model;
+    // second pass after the pipeline (deferred_count != nullptr): nothing to do in the common case
+    const bool only_deferred = deferred_count != nullptr;
+    if (only_deferred && deferred_count[0] == 0) return;
+    const SmplxModelDev* M;
     const SmplxActionsDev& A = S->actions;
-    ThreadLds L = setup_lds(M, smem);
+    ThreadLds L = setup_lds(&S->model, smem, &M);
+    const SmplxGridDev grid = S->grid;
+    const SmplxBfsDev bfs = S->bfs;
     const int nprims = A.nprims;
     const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const bool in_range = tid < (long long)B * nprims;
+    bool in_range = tid < (long long)B * nprims;
+    // second pass after the pipeline: only the edges it deferred (they did not fit the work list)
+    if (only_deferred && in_range && !(out_flags[tid] & SMPLX_F_DEFERRED)) in_range = false;
     int flags = SMPLX_F_INACTIVE;
     int lookups = 0;
+    int performed = 0;   // lookups this kernel itself issued (waypoints >= 1)
     int evaluated = 0;
     if (in_range) {
         const int si = (int)(tid / nprims);
@@ -579,8 +655,11 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
             } else {
                 int W = 0;
                 int lk = 0;
-                const bool ok = edge_valid(M, L, S->grid, parent, sq, true, parent_valid[si] != 0, lk, W);
+                // fused mode: parent_valid holds 1 = valid (k_state_prep); deferred pass: the pipeline's state_bad (1 = bad)
+                const bool pv = only_deferred ? parent_valid[si] == 0 : parent_valid[si] != 0;
+                const bool ok = edge_valid(M, L, grid, parent, sq, true, pv, lk, W);
                 lookups = lk;
+                performed = lk;
                 if (W > 0) lookups += parent_lookups[si];   // waypoint 0, done once per state by k_state_prep
                 if (!ok) {
                     flags = SMPLX_F_COLLISION;
@@ -599,8 +678,8 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
                                   fabs(p[2] - S->goal.xyz[2]) <= S->goal.xyz_tol[2];
                     }
                     int c[3];
-                    world_to_cell(S->grid, p, c);
-                    h = bfs_cost_to_goal(S->bfs, c);
+                    world_to_cell(grid, p, c);
+                    h = bfs_cost_to_goal(bfs, c);
                     cost = A.cost[pi];
                     flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
                 }
@@ -615,13 +694,279 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
     if (counters) {
         const unsigned long long m_eval = __ballot(evaluated);
         const unsigned long long m_valid = __ballot((flags & SMPLX_F_VALID) != 0);
-        int lk = lookups;
-        for (int off = 32; off > 0; off >>= 1) lk += __shfl_down(lk, off);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&counters[0], (unsigned long long)__popcll(m_eval));
-            atomicAdd(&counters[1], (unsigned long long)__popcll(m_valid));
-            atomicAdd(&counters[2], (unsigned long long)lk);
+        tally_block(counters, __popcll(m_eval), __popcll(m_valid), lookups, performed, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Waypoint-parallel pipeline (default).  The fused k_expand above walks an edge's waypoints one
+// after another inside one thread, which leaves the chip idle at B = 4096 (about 1.6 waves per
+// SIMD, each a serial fp64 chain).  The pipeline spreads the same work over (edge, waypoint) items:
+//   k_pipe_prep    per state: planning-link FK -> metric goal distance
+//   k_pipe_setup   per (state, primitive): gating, successor joint values, limits, waypoint count;
+//                  claims a range of the work list with one atomic per wave (ballot + prefix count)
+//   k_pipe_configs per work item: one configuration against the grid and the link pairs;
+//                  items [0, B) are the states themselves (waypoint 0 of every edge)
+//   k_pipe_finish  per (state, primitive): verdict, discretisation, goal test, heuristic, cost
+// Booleans, coordinates, heuristics and costs are identical to k_expand.  Without the serial
+// early exit a colliding edge has all its waypoints examined, so the lookup tally of an INVALID
+// edge can exceed the reference's; for valid edges it is identical.
+// ---------------------------------------------------------------------------------------------
+
+#define SMPLX_WP_BITS 10
+#define SMPLX_WP_MAX ((1 << SMPLX_WP_BITS) - 1)
+#define SMPLX_WORK_SHARDS 8
+#define SMPLX_SHARD_STRIDE 32   // ints: one 128-byte line per shard counter
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+            double* __restrict__ goal_dist, int* __restrict__ work_count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = setup_model_only(&S->model, smem);
+    const SmplxGridDev grid = S->grid;
+    const SmplxBfsDev bfs = S->bfs;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i <= SMPLX_WORK_SHARDS) work_count[i * SMPLX_SHARD_STRIDE] = 0;   // shard counters + deferred count
+    if (i >= B) return;
+    const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
+    double p[3];
+    planning_fk(M, q, p);
+    int c[3];
+    world_to_cell(grid, p, c);
+    goal_dist[i] = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+             const double* __restrict__ goal_dist, unsigned char* __restrict__ out_flags, double* __restrict__ out_q,
+             int* __restrict__ edge_w, int* __restrict__ edge_lookups, unsigned char* __restrict__ edge_bad,
+             int* __restrict__ state_lookups, unsigned char* __restrict__ state_bad,
+             unsigned int* __restrict__ work, int* __restrict__ work_count, int capacity)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = setup_model_only(&S->model, smem);
+    const SmplxActionsDev& A = S->actions;
+    const int nprims = A.nprims;
+    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool in_range = tid < (long long)B * nprims;
+    int items = 0;
+    int W = 0;
+    int flags = SMPLX_F_INACTIVE;
+    if (in_range) {
+        const int si = (int)(tid / nprims);
+        const int pi = (int)(tid - (long long)si * nprims);
+        const int nv = M->nvars;
+        const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
+        double* sq = out_q + tid * nv;
+        const int type = A.type[pi];
+        bool have_action = false;
+        if (pi == 0) { state_lookups[si] = 0; state_bad[si] = 0; }
+        if (mprim_active(A, goal_dist[si], type)) {
+            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+                double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
+                if (A.xy_rotate_by_var3 && nv > 3) {
+                    double s, c;
+                    smplx_sincos(parent[3], &s, &c);
+                    const double a0 = d0, a1 = d1;
+                    d0 = c * a0 + (-s) * a1;
+                    d1 = s * a0 + c * a1;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
+                    sq[v] = d + parent[v];
+                }
+                have_action = true;
+            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && S->goal.type == SMPLX_GOAL_JOINT) {
+                for (int v = 0; v < nv; ++v) sq[v] = S->goal.angles[v];
+                have_action = true;
+            }
         }
+        if (have_action) {
+            flags = 0;
+            if (!check_joint_limits(M, sq)) {
+                flags = SMPLX_F_LIMITS;
+            } else {
+                double motion = 0.0;
+                for (int v = 0; v < nv; ++v) {
+                    const int ty = M->var_type[v];
+                    const double sv = parent[v], fv = sq[v];
+                    if (ty == SMPLX_JT_CONTINUOUS) motion += M->var_k[v] * fabs(smplx_shortest_angle_diff(fv, sv));
+                    else if (ty == SMPLX_JT_REVOLUTE) motion += M->var_k[v] * fabs(fv - sv);
+                    else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
+                }
+                if (motion != 0.0) {
+                    W = (int)ceil(motion / 0.05) + 1;
+                    if (W < 2) W = 2;
+                }
+                items = W > 0 ? W - 1 : 0;
+            }
+        }
+        edge_lookups[tid] = 0;
+        edge_bad[tid] = 0;
+    }
+    // claim a contiguous range of the work list.  Same-address atomics serialise at ~12 ns each on this
+    // chip, so: wave prefix count (shuffles) -> block total through LDS -> ONE atomic per block, spread over
+    // SMPLX_WORK_SHARDS counters that live on separate 128-byte lines.
+    __shared__ int wave_sum[BLOCK / 64];
+    __shared__ int block_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = items;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_sum[wv] = incl;
+    __syncthreads();
+    const int shard = blockIdx.x % SMPLX_WORK_SHARDS;
+    const int shard_cap = capacity / SMPLX_WORK_SHARDS;
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < BLOCK / 64; ++k) tot += wave_sum[k];
+        block_base = tot > 0 ? atomicAdd(&work_count[shard * SMPLX_SHARD_STRIDE], tot) : 0;
+    }
+    __syncthreads();
+    int first = block_base + incl - items;
+    for (int k = 0; k < wv; ++k) first += wave_sum[k];
+    if (in_range) {
+        if (items > 0) {
+            unsigned int* wl = work + (size_t)shard * shard_cap;
+            if (first + items <= shard_cap && W - 1 <= SMPLX_WP_MAX) {
+                for (int k = 0; k < items; ++k) wl[first + k] = ((unsigned int)tid << SMPLX_WP_BITS) | (unsigned int)(k + 1);
+            } else {
+                // does not fit: deferred to a fused pass (k_expand, SMPLX_F_DEFERRED); blank the part of the claim
+                // that lies below the shard's capacity
+                for (int k = first; k < first + items && k < shard_cap; ++k) wl[k] = 0xFFFFFFFFu;
+                flags = SMPLX_F_DEFERRED;
+                atomicAdd(&work_count[SMPLX_WORK_SHARDS * SMPLX_SHARD_STRIDE], 1);
+            }
+        }
+        edge_w[tid] = W;
+        out_flags[tid] = (unsigned char)flags;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+               const double* __restrict__ out_q, const int* __restrict__ edge_w, int* __restrict__ edge_lookups,
+               unsigned char* __restrict__ edge_bad, int* __restrict__ state_lookups, unsigned char* __restrict__ state_bad,
+               const unsigned int* __restrict__ work, const int* __restrict__ work_count, int capacity)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int shard_cap = capacity / SMPLX_WORK_SHARDS;
+    int pre[SMPLX_WORK_SHARDS + 1];   // prefix of the shard fill counts (claims beyond a shard's capacity were never written)
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < SMPLX_WORK_SHARDS; ++k) {
+        int c = work_count[k * SMPLX_SHARD_STRIDE];
+        if (c > shard_cap) c = shard_cap;
+        pre[k + 1] = pre[k] + c;
+    }
+    const long long total = (long long)B + pre[SMPLX_WORK_SHARDS];
+    if ((long long)blockIdx.x * BLOCK >= total) return;   // whole block idle: skip staging the model
+    const SmplxModelDev* M;
+    ThreadLds L = setup_lds(&S->model, smem, &M);
+    const SmplxGridDev grid = S->grid;
+    const int nprims = S->actions.nprims;
+    const int nv = M->nvars;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * BLOCK) {
+        EdgeRef e;
+        int lk = 0;
+        if (i < B) {   // the state itself: waypoint 0 of each of its edges
+            e.start = Q + (refs ? refs[i] : i) * nv;
+            e.finish = e.start;
+            e.alpha = 0.0;
+            const bool ok = config_valid(M, L, grid, e, lk);
+            state_lookups[i] = lk;
+            if (!ok) state_bad[i] = 1;
+        } else {
+            const int li = (int)(i - B);
+            int sh = 0;
+#pragma unroll
+            for (int k = 1; k < SMPLX_WORK_SHARDS; ++k) sh += (li >= pre[k]) ? 1 : 0;
+            const unsigned int it = work[(size_t)sh * shard_cap + (li - pre[sh])];
+            if (it == 0xFFFFFFFFu) continue;
+            const long long edge = it >> SMPLX_WP_BITS;
+            const int wp = (int)(it & SMPLX_WP_MAX);
+            const int si = (int)(edge / nprims);
+            const int W = edge_w[edge];
+            e.start = Q + (refs ? refs[si] : (int64_t)si) * nv;
+            e.finish = out_q + edge * nv;
+            e.alpha = (double)wp * (1.0 / (double)(W - 1));
+            const bool ok = config_valid(M, L, grid, e, lk);
+            atomicAdd(&edge_lookups[edge], lk);
+            if (!ok) edge_bad[edge] = 1;
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+              const int* __restrict__ edge_w, const int* __restrict__ edge_lookups, const unsigned char* __restrict__ edge_bad,
+              const int* __restrict__ state_lookups, const unsigned char* __restrict__ state_bad,
+              unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
+              int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
+              unsigned long long* __restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SmplxModelDev* M = setup_model_only(&S->model, smem);
+    const SmplxActionsDev& A = S->actions;
+    const SmplxGridDev grid = S->grid;
+    const SmplxBfsDev bfs = S->bfs;
+    const int nprims = A.nprims;
+    const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool in_range = tid < (long long)B * nprims;
+    int flags = SMPLX_F_INACTIVE, lookups = 0, performed = 0, evaluated = 0;
+    int ncfg = 0, slk = 0;   // configurations k_pipe_configs checked for this edge / lookups of the state's own check
+    if (in_range) {
+        const int si = (int)(tid / nprims);
+        const int pi = (int)(tid - (long long)si * nprims);
+        const int nv = M->nvars;
+        flags = out_flags[tid];
+        if (pi == 0) { slk = state_lookups[si]; ncfg = 1; }
+        int h = 0, cost = 0;
+        if (!(flags & (SMPLX_F_INACTIVE | SMPLX_F_DEFERRED))) evaluated = 1;   // deferred edges are tallied by the fused pass
+        if (flags == 0) {
+            const int W = edge_w[tid];
+            if (W > 0) ncfg += W - 1;
+            performed = edge_lookups[tid];
+            const bool ok = (W == 0) || (state_bad[si] == 0 && edge_bad[tid] == 0);
+            lookups = performed + (W > 0 ? state_lookups[si] : 0);
+            if (!ok) {
+                flags = SMPLX_F_COLLISION;
+            } else {
+                const double* sq = out_q + tid * nv;
+                int* sc = out_coord + tid * nv;
+                for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
+                double p[3];
+                planning_fk(M, sq, p);
+                bool is_goal;
+                if (S->goal.type == SMPLX_GOAL_JOINT) {
+                    is_goal = true;
+                    for (int v = 0; v < nv; ++v)
+                        if (fabs((double)(sc[v] - S->goal.coord[v])) > S->goal.angle_tol[v]) is_goal = false;
+                } else {
+                    is_goal = fabs(p[0] - S->goal.xyz[0]) <= S->goal.xyz_tol[0] &&
+                              fabs(p[1] - S->goal.xyz[1]) <= S->goal.xyz_tol[1] &&
+                              fabs(p[2] - S->goal.xyz[2]) <= S->goal.xyz_tol[2];
+                }
+                int c[3];
+                world_to_cell(grid, p, c);
+                h = bfs_cost_to_goal(bfs, c);
+                cost = A.cost[pi];
+                flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
+            }
+        }
+        out_flags[tid] = (unsigned char)flags;
+        out_h[tid] = h;
+        out_cost[tid] = cost;
+        out_lookups[tid] = lookups;
+    }
+    if (counters) {
+        const unsigned long long m_eval = __ballot(evaluated);
+        const unsigned long long m_valid = __ballot((flags & SMPLX_F_VALID) != 0);
+        tally_block(counters, __popcll(m_eval), __popcll(m_valid), lookups, performed, ncfg, slk);
     }
 }
 
@@ -630,12 +975,13 @@ k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq,
              unsigned char* __restrict__ out, int* __restrict__ out_lookups, int* __restrict__ out_waypoints)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = &S->model;
-    ThreadLds L = setup_lds(M, smem);
+    const SmplxModelDev* M;
+    ThreadLds L = setup_lds(&S->model, smem, &M);
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     int lk = 0, W = 0;
-    const bool ok = edge_valid(M, L, S->grid, Aq + (size_t)i * M->nvars, Bq + (size_t)i * M->nvars, false, true, lk, W);
+    const SmplxGridDev grid = S->grid;
+    const bool ok = edge_valid(M, L, grid, Aq + (size_t)i * M->nvars, Bq + (size_t)i * M->nvars, false, true, lk, W);
     out[i] = ok ? 1 : 0;
     if (out_lookups) out_lookups[i] = lk;
     if (out_waypoints) out_waypoints[i] = W;
@@ -646,14 +992,15 @@ k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               int* __restrict__ out_lookups)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = &S->model;
-    ThreadLds L = setup_lds(M, smem);
+    const SmplxModelDev* M;
+    ThreadLds L = setup_lds(&S->model, smem, &M);
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     EdgeRef e;
     e.start = Q + (size_t)i * M->nvars; e.finish = e.start; e.alpha = 0.0;
     int lk = 0;
-    const bool ok = config_valid(M, L, S->grid, e, lk);
+    const SmplxGridDev grid = S->grid;
+    const bool ok = config_valid(M, L, grid, e, lk);
     out[i] = ok ? 1 : 0;
     if (out_lookups) out_lookups[i] = lk;
 }
@@ -678,8 +1025,8 @@ extern "C" __global__ void __launch_bounds__(BLOCK)
 k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, double* __restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = &S->model;
-    ThreadLds L = setup_lds(M, smem);
+    const SmplxModelDev* M;
+    ThreadLds L = setup_lds(&S->model, smem, &M);
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const double* q = Q + (size_t)i * M->nvars;

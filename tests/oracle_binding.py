@@ -205,6 +205,15 @@ class Oracle:
                                 _p(cost, _ip), _p(lk, _ip))
         return dict(flags=flags, coord=coord, q=sq, h=h, cost=cost, lookups=lk)
 
+    def eval_batch_timed(self, Q, min_seconds):
+        Q = np.ascontiguousarray(Q, np.float64).reshape(-1, self.N)
+        ev, va = C.c_long(), C.c_long(); sec = C.c_double(); ps = C.c_int()
+        self.lib.orc_eval_batch_timed.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double, C.POINTER(C.c_long),
+                                                  C.POINTER(C.c_long), _dp, _ip]
+        self.lib.orc_eval_batch_timed(self.h, _p(Q, _dp), Q.shape[0], float(min_seconds), C.byref(ev), C.byref(va),
+                                      C.byref(sec), C.byref(ps))
+        return dict(evals=ev.value, valid=va.value, seconds=sec.value, passes=ps.value)
+
     # --- search ---
     def search_params(self, eps0, eps_final, eps_delta, improve=True, bounded=False, max_init=0, max_rep=0):
         self.lib.orc_search_params(self.h, eps0, eps_final, eps_delta, int(improve), int(bounded), max_init, max_rep)
