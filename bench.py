@@ -32,6 +32,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def rank_goal_shift(rank: int):
+    """Goal offset (whole lattice cells) of rank r's query: independent queries on the replicated scene.
+    Joints 4-6 move in multiples of 4 cells so the goal stays on the lattice the short primitives reach."""
+    if rank == 0:
+        return [0] * 7
+    return [(-3 * rank) % 17 - 8, (2 * rank) % 9 - 4, (5 * rank) % 13 - 6, (-rank) % 7 - 3, 4 * (rank % 5 - 2),
+            4 * (rank % 3 - 1), 4 * (rank % 7 - 3)]
+
+
+def gather_records(rec, dist, world):
+    """All-gather of the per-rank result record (RCCL on GPUs, gloo in the CPU test); the only collective."""
+    import torch
+    if dist is None or world == 1:
+        return rec.detach().cpu().numpy()[None]
+    allrec = [torch.zeros_like(rec) for _ in range(world)]
+    dist.all_gather(allrec, rec)
+    return torch.stack(allrec).cpu().numpy()
+
+
+def aggregate(allrec):
+    """Whole-job throughput: units of all ranks / max-over-ranks time."""
+    total = float(allrec[:, 0].sum())
+    tmax = float(allrec[:, 1].max())
+    return total / tmax, tmax, total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,9 +91,7 @@ def main():
     cfg = scenes.config2(n=args.grid)
     goal = list(cfg.goal)
     if rank > 0:   # independent queries: shift the goal by whole lattice cells, keep it reachable
-        shift = [(-3 * rank) % 17 - 8, (2 * rank) % 9 - 4, (5 * rank) % 13 - 6, (-rank) % 7 - 3, 4 * (rank % 5 - 2),
-                 4 * (rank % 3 - 1), 4 * (rank % 7 - 3)]
-        goal = [g + c * scenes.DEG for g, c in zip(goal, shift)]
+        goal = [g + c * scenes.DEG for g, c in zip(goal, rank_goal_shift(rank))]
     space = capi.Space.from_config(cfg, batch_states=args.batch)
     ok, _ = space.state_valid_batch(np.array([goal]))
     if not ok[0]:
@@ -121,15 +145,8 @@ def main():
 
     # ---- whole-job aggregate: max time over ranks, sum of units ----
     rec = torch.tensor([float(evals), elapsed, float(valid)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        allrec = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)   # RCCL all-gather of the per-rank result records
-        allrec = torch.stack(allrec).cpu().numpy()
-    else:
-        allrec = rec.cpu().numpy()[None]
-    total_evals = float(allrec[:, 0].sum())
-    tmax = float(allrec[:, 1].max())
-    value = total_evals / tmax
+    allrec = gather_records(rec, dist, world)   # RCCL all-gather of the per-rank result records
+    value, tmax, total_evals = aggregate(allrec)
 
     # ---- roofline of the dominant kernel (k_pipe_configs: the collision check), this rank ----
     # SURVEY 8(d), collision kernel: algorithmic bytes = 4 B per distance-grid lookup + 8N B per configuration.

@@ -1,0 +1,216 @@
+// include/smpl_amd/plugin.hpp -- C++ mirror of smpl's plugin interfaces for the expansion path,
+// implemented over the C-ABI (include/smpl_amd.h).  Header-only; link with libsmpl_amd.so.
+//
+// Same class and method names, argument meaning and error behaviour (bool success, empty successor list
+// = dead end) as the reference, minus Eigen/ROS/SBPL types:
+//   CollisionChecker     smpl/include/smpl/collision_checker.h:48-130
+//   RobotHeuristic       smpl/include/smpl/heuristic/robot_heuristic.h:53-101
+//   RobotPlanningSpace   smpl/include/smpl/graph/robot_planning_space.h:60-218
+//                        (+ SBPL DiscreteSpaceInformation::GetSuccs, Heuristic::GetGoalHeuristic)
+//   Extension            smpl/include/smpl/extension.h:40-60
+// In a real integration these classes derive from the reference's own bases; the bodies
+// stay as they are here.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+#include <vector>
+
+#include "../smpl_amd.h"
+
+namespace smpl_amd {
+
+typedef std::vector<double> RobotState;   // smpl/include/smpl/types.h:66
+
+// smpl/include/smpl/extension.h:40-60
+class Extension {
+public:
+    virtual ~Extension() {}
+    template <class T> T* getExtension() { return dynamic_cast<T*>(getExtension(typeid(T).hash_code())); }
+    virtual Extension* getExtension(size_t class_code) = 0;
+};
+template <class T> inline size_t GetClassCode() { return typeid(T).hash_code(); }
+
+// smpl/include/smpl/collision_checker.h:48-130
+class CollisionChecker : public virtual Extension {
+public:
+    virtual bool isStateValid(const RobotState& state, bool verbose = false) = 0;
+    virtual bool isStateToStateValid(const RobotState& start, const RobotState& finish, bool verbose = false) = 0;
+    virtual bool interpolatePath(const RobotState& start, const RobotState& finish, std::vector<RobotState>& path) = 0;
+};
+
+// SBPL Heuristic + smpl/include/smpl/heuristic/robot_heuristic.h:53-101
+class RobotHeuristic : public virtual Extension {
+public:
+    virtual int GetGoalHeuristic(int state_id) = 0;
+    virtual int GetStartHeuristic(int state_id) = 0;
+    virtual int GetFromToHeuristic(int from_id, int to_id) = 0;
+    virtual double getMetricGoalDistance(double x, double y, double z) = 0;
+    virtual double getMetricStartDistance(double x, double y, double z) = 0;
+};
+
+// SBPL DiscreteSpaceInformation + smpl/include/smpl/graph/robot_planning_space.h:60-218
+class RobotPlanningSpace : public virtual Extension {
+public:
+    virtual bool setStart(const RobotState& state) = 0;
+    virtual int getStartStateID() const = 0;
+    virtual int getGoalStateID() const = 0;
+    virtual bool extractPath(const std::vector<int>& ids, std::vector<RobotState>& path) = 0;
+    virtual void GetSuccs(int state_id, std::vector<int>* succs, std::vector<int>* costs) = 0;
+    virtual void GetPreds(int state_id, std::vector<int>* preds, std::vector<int>* costs) = 0;
+    virtual int GetGoalHeuristic(int state_id) = 0;
+};
+
+// One query context on one GPU.  Owns the C-ABI handles; the three plugin facades below share it, the
+// way the reference's lattice, heuristic and checker share one OccupancyGrid and one RobotModel.
+class GpuPlanningContext {
+public:
+    GpuPlanningContext(const std::string& robot_text, const std::string& mprim_text, const double origin[3], int nx, int ny,
+                       int nz, double res, double max_dist, const int32_t* d2, const smplx_params& params)
+    {
+        check(smplx_grid_create(origin, nx, ny, nz, res, max_dist, d2, &grid_));
+        check(smplx_model_create(robot_text.c_str(), &model_));
+        check(smplx_space_create(model_, grid_, mprim_text.c_str(), &params, &space_));
+        nvars_ = smplx_space_num_vars(space_);
+        nprims_ = smplx_space_num_prims(space_);
+        res_ = res;
+    }
+    ~GpuPlanningContext()
+    {
+        smplx_space_destroy(space_);
+        smplx_model_destroy(model_);
+        smplx_grid_destroy(grid_);
+    }
+    GpuPlanningContext(const GpuPlanningContext&) = delete;
+    GpuPlanningContext& operator=(const GpuPlanningContext&) = delete;
+    smplx_space* space() const { return space_; }
+    int nvars() const { return nvars_; }
+    int nprims() const { return nprims_; }
+    double resolution() const { return res_; }
+    static void check(int code)
+    {
+        if (code != SMPLX_OK) throw std::runtime_error(std::string("smpl_amd: ") + smplx_last_error());
+    }
+
+private:
+    smplx_grid* grid_ = nullptr;
+    smplx_model* model_ = nullptr;
+    smplx_space* space_ = nullptr;
+    int nvars_ = 0, nprims_ = 0;
+    double res_ = 0.0;
+};
+
+// sbpl::collision::CollisionSpace (sbpl_collision_checking/include/sbpl_collision_checking/collision_space.h:66-266)
+class GpuCollisionChecker : public CollisionChecker {
+public:
+    explicit GpuCollisionChecker(GpuPlanningContext* ctx) : ctx_(ctx) {}
+    bool isStateValid(const RobotState& state, bool = false) override
+    {
+        uint8_t ok = 0;
+        return smplx_cc_state_valid_batch(ctx_->space(), state.data(), 1, &ok, nullptr) == SMPLX_OK && ok;
+    }
+    bool isStateToStateValid(const RobotState& start, const RobotState& finish, bool = false) override
+    {
+        uint8_t ok = 0;
+        return smplx_cc_edge_valid_batch(ctx_->space(), start.data(), finish.data(), 1, &ok, nullptr, nullptr) == SMPLX_OK && ok;
+    }
+    // batched forms: what a frontier-batched caller uses instead of one call per edge
+    bool areStatesToStatesValid(const std::vector<double>& starts, const std::vector<double>& finishes, std::vector<uint8_t>& ok)
+    {
+        const int n = (int)(starts.size() / ctx_->nvars());
+        ok.assign(n, 0);
+        return smplx_cc_edge_valid_batch(ctx_->space(), starts.data(), finishes.data(), n, ok.data(), nullptr, nullptr) == SMPLX_OK;
+    }
+    bool interpolatePath(const RobotState& start, const RobotState& finish, std::vector<RobotState>& path) override
+    {
+        int n = 0;
+        if (smplx_cc_interpolate(ctx_->space(), start.data(), finish.data(), nullptr, 0, &n) != SMPLX_OK) return false;
+        std::vector<double> buf((size_t)n * ctx_->nvars());
+        if (smplx_cc_interpolate(ctx_->space(), start.data(), finish.data(), buf.data(), n, &n) != SMPLX_OK) return false;
+        path.clear();
+        for (int i = 0; i < n; ++i) path.emplace_back(buf.begin() + (size_t)i * ctx_->nvars(), buf.begin() + (size_t)(i + 1) * ctx_->nvars());
+        return true;
+    }
+    Extension* getExtension(size_t class_code) override
+    {
+        return class_code == GetClassCode<CollisionChecker>() ? this : nullptr;   // collision_space.cpp:523-529
+    }
+
+private:
+    GpuPlanningContext* ctx_;
+};
+
+// sbpl::motion::ManipLattice (smpl/include/smpl/graph/manip_lattice.h:63-307)
+class GpuManipLattice : public RobotPlanningSpace {
+public:
+    explicit GpuManipLattice(GpuPlanningContext* ctx) : ctx_(ctx) {}
+    // GoalConstraint with JOINT_STATE_GOAL / XYZ_GOAL (manip_lattice.cpp:1982-1997); observers (the BFS
+    // heuristic) are notified inside the engine: BFS_3D::run completes before this returns
+    bool setGoalConfiguration(const RobotState& angles, const RobotState& tolerances)
+    {
+        return smplx_set_goal_joint(ctx_->space(), angles.data(), tolerances.data()) == SMPLX_OK;
+    }
+    bool setGoalPosition(const double xyz[3], const double tol[3]) { return smplx_set_goal_xyz(ctx_->space(), xyz, tol) == SMPLX_OK; }
+    bool setStart(const RobotState& state) override { return smplx_set_start(ctx_->space(), state.data(), nullptr) == SMPLX_OK; }
+    int getStartStateID() const override { return smplx_start_id(ctx_->space()); }
+    int getGoalStateID() const override { return smplx_goal_id(ctx_->space()); }
+    void GetSuccs(int state_id, std::vector<int>* succs, std::vector<int>* costs) override
+    {
+        const int cap = ctx_->nprims();
+        std::vector<int32_t> s(cap), c(cap);
+        int n = 0;
+        if (smplx_get_succs(ctx_->space(), state_id, s.data(), c.data(), cap, &n) != SMPLX_OK) return;   // dead end on error
+        succs->insert(succs->end(), s.begin(), s.begin() + n);
+        costs->insert(costs->end(), c.begin(), c.begin() + n);
+    }
+    void GetPreds(int, std::vector<int>*, std::vector<int>*) override {}   // "GetPreds unimplemented" (manip_lattice.cpp:1238-1241)
+    int GetGoalHeuristic(int state_id) override
+    {
+        int32_t h = 0;
+        return smplx_get_goal_heuristic(ctx_->space(), state_id, &h) == SMPLX_OK ? h : 0;
+    }
+    // optional, not in the reference: ids the search will expand soon ride along in the next frontier batch
+    void hintFrontier(const std::vector<int>& ids) { smplx_hint_frontier(ctx_->space(), ids.data(), (int)ids.size()); }
+    bool extractPath(const std::vector<int>& ids, std::vector<RobotState>& path) override
+    {
+        std::vector<double> q(ids.size() * (size_t)ctx_->nvars());
+        if (smplx_extract_path(ctx_->space(), ids.data(), (int)ids.size(), q.data()) != SMPLX_OK) return false;
+        path.clear();
+        for (size_t i = 0; i < ids.size(); ++i) path.emplace_back(q.begin() + i * ctx_->nvars(), q.begin() + (i + 1) * ctx_->nvars());
+        return true;
+    }
+    Extension* getExtension(size_t class_code) override
+    {
+        return class_code == GetClassCode<RobotPlanningSpace>() ? this : nullptr;   // manip_lattice.cpp:2157-2170
+    }
+
+private:
+    GpuPlanningContext* ctx_;
+};
+
+// sbpl::motion::BfsHeuristic (smpl/include/smpl/heuristic/bfs_heuristic.h:49-105)
+class GpuBfsHeuristic : public RobotHeuristic {
+public:
+    explicit GpuBfsHeuristic(GpuPlanningContext* ctx) : ctx_(ctx) {}
+    int GetGoalHeuristic(int state_id) override
+    {
+        int32_t h = 0;
+        return smplx_get_goal_heuristic(ctx_->space(), state_id, &h) == SMPLX_OK ? h : 0;
+    }
+    int GetStartHeuristic(int) override { return 0; }         // "unimplemented" in the reference (bfs_heuristic.cpp:165-169)
+    int GetFromToHeuristic(int, int to_id) override { return GetGoalHeuristic(to_id); }
+    double getMetricGoalDistance(double, double, double) override { return 0.0; }   // used only inside the engine's gating
+    double getMetricStartDistance(double, double, double) override { return 0.0; }
+    Extension* getExtension(size_t class_code) override
+    {
+        return class_code == GetClassCode<RobotHeuristic>() ? this : nullptr;       // bfs_heuristic.cpp:140-146
+    }
+
+private:
+    GpuPlanningContext* ctx_;
+};
+
+}  // namespace smpl_amd

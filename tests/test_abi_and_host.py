@@ -1,0 +1,100 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/smpl_amd.h
+declares, the host model compiler agrees bit for bit with the oracle, errors map to codes, and the
+library refuses to work without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_binding import Oracle
+from smpl_amd import capi, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "smpl_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(smplx_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 40
+    L = capi.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(capi.SYMBOLS) == declared   # the Python binding knows exactly the header's entry points
+
+
+@pytest.mark.parametrize("robot", [scenes.arm7_robot, scenes.dual_arm14_robot])
+def test_host_model_compiler_matches_oracle_bitwise(robot, small_cfg):
+    import copy
+    cfg = copy.copy(small_cfg)
+    cfg.robot_text = robot()
+    if robot is scenes.dual_arm14_robot:
+        cfg.params = scenes.PlanningParams([scenes.DEG] * 14)
+        cfg.mprim = scenes.mprim_text(14, range(14), range(14))
+    om = Oracle(cfg).model()
+    m = capi.Model(cfg.robot_text)
+    pm = m.arrays()
+    fi = pm["file_index"]
+    assert np.array_equal(pm["origins"], om["origins"][fi])      # joint origins (rpy -> matrix)
+    assert np.array_equal(pm["k"], om["k"][fi])                  # motion-sphere factors |c| + r
+    assert np.array_equal(pm["xyzr"], om["xyzr"])                # sphere trees: centres and radii, node order
+    first = om["tree_first"]
+    ol, orr = om["left"].copy(), om["right"].copy()
+    for t in range(len(first) - 1):
+        sl = slice(first[t], first[t + 1])
+        ol[sl] = np.where(ol[sl] >= 0, ol[sl] + first[t], -1)
+        orr[sl] = np.where(orr[sl] >= 0, orr[sl] + first[t], -1)
+    assert np.array_equal(ol, pm["left"]) and np.array_equal(orr, pm["right"])
+    assert np.array_equal(first, pm["tree_first"])
+    assert np.array_equal(om["pairs"], pm["pairs"])
+    if robot is scenes.arm7_robot:
+        assert (m.njoints, m.nvars, m.ntrees, m.nnodes, m.npairs, m.nslots) == (13, 7, 8, 38, 11, 1)
+        leaves = int((pm["left"] < 0).sum())
+        assert leaves == 23                                       # trees of 1,4,7,3,2,2,2,2 leaves
+    else:
+        assert m.nvars == 14 and m.ntrees == 16 and int((pm["left"] < 0).sum()) == 46
+
+
+def test_parse_errors_and_limits_map_to_codes():
+    with pytest.raises(capi.SmplxError) as e:
+        capi.Model("link a\njoint j bogus a b 0 0 0 0 0 0 0 0 1 0 0\n")
+    assert e.value.code == -2
+    with pytest.raises(capi.SmplxError) as e:
+        capi.Model("link a\nlink b\njoint j fixed a c 0 0 0 0 0 0 0 0 1 0 0\n")
+    assert e.value.code == -2 and "unknown link" in str(e.value)
+    too_many = "link l0\n" + "".join(
+        f"link l{i}\njoint j{i} fixed l{i-1} l{i} 0 0 0 0 0 0 0 0 1 0 0\n" for i in range(1, 60))
+    with pytest.raises(capi.SmplxError) as e:
+        capi.Model(too_many)
+    assert e.value.code == -3
+
+
+def test_no_cpu_fallback_without_gpu(small_cfg):
+    if capi.lib().smplx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.SmplxError) as e:
+        capi.Space.from_config(small_cfg)
+    assert e.value.code == -4           # SMPLX_E_HIP: fails loudly, never computes on the CPU
+
+
+def test_scene_generator_is_deterministic_and_exact(small_cfg):
+    again = scenes.config_small()
+    assert np.array_equal(again.grid.d2, small_cfg.grid.d2)
+    # exact EDT with border cells as obstacles, capped (distance_map.hpp:560-606 border, :126-127 cap)
+    g = small_cfg.grid
+    dmax = g.dmax_int
+    rng = np.random.default_rng(5)
+    occ = g.d2 == 0
+    pts = np.argwhere(occ)
+    for _ in range(40):
+        c = rng.integers(0, g.dims[0], 3)
+        best = min(int(((pts - c) ** 2).sum(1).min()) if len(pts) else 10 ** 9,
+                   min(int(c[a] + 1) ** 2 for a in range(3)), min(int(g.dims[a] - c[a]) ** 2 for a in range(3)))
+        assert g.d2[tuple(c)] == min(best, dmax * dmax)
+
+
+def test_mprim_text_round_trip_against_oracle(small_cfg):
+    o = Oracle(small_cfg)
+    assert o.M == 25            # 3 adaptive slots + (4 long + 7 short) x 2 (converse), pr2.mprim layout
+    assert o.N == 7
