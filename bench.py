@@ -157,8 +157,16 @@ def main():
     alg_bytes = 4.0 * lk_per_launch + 8.0 * N * cfg_per_launch
     k_ms = prep_ms / L_            # first event interval = k_pipe_configs
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # HBM-side bytes of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    # runs; gfx950 correction applied) -- kept in profiles/traffic.json, null when that file is absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f)["k_pipe_configs"]["bytes_per_launch"] if args.batch == 4096 and args.grid == 256 else None
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None, "kernel": "k_pipe_configs",
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "kernel": "k_pipe_configs",
                 "kernel_ms": round(k_ms, 4), "finish_kernel_ms": round(expand_ms / L_, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes), "configs_per_launch": int(cfg_per_launch),
                 "lookups_per_launch": int(lk_per_launch), "evals_per_launch": int(evals / L_),

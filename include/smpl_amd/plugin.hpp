@@ -106,6 +106,7 @@ private:
 // sbpl::collision::CollisionSpace (sbpl_collision_checking/include/sbpl_collision_checking/collision_space.h:66-266)
 class GpuCollisionChecker : public CollisionChecker {
 public:
+    using Extension::getExtension;   // keep the typed lookup visible next to the override
     explicit GpuCollisionChecker(GpuPlanningContext* ctx) : ctx_(ctx) {}
     bool isStateValid(const RobotState& state, bool = false) override
     {
@@ -146,6 +147,7 @@ private:
 // sbpl::motion::ManipLattice (smpl/include/smpl/graph/manip_lattice.h:63-307)
 class GpuManipLattice : public RobotPlanningSpace {
 public:
+    using Extension::getExtension;   // keep the typed lookup visible next to the override
     explicit GpuManipLattice(GpuPlanningContext* ctx) : ctx_(ctx) {}
     // GoalConstraint with JOINT_STATE_GOAL / XYZ_GOAL (manip_lattice.cpp:1982-1997); observers (the BFS
     // heuristic) are notified inside the engine: BFS_3D::run completes before this returns
@@ -194,6 +196,7 @@ private:
 // sbpl::motion::BfsHeuristic (smpl/include/smpl/heuristic/bfs_heuristic.h:49-105)
 class GpuBfsHeuristic : public RobotHeuristic {
 public:
+    using Extension::getExtension;   // keep the typed lookup visible next to the override
     explicit GpuBfsHeuristic(GpuPlanningContext* ctx) : ctx_(ctx) {}
     int GetGoalHeuristic(int state_id) override
     {
