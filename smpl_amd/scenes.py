@@ -304,9 +304,9 @@ def config_small(n: int = 64, seed: int = 7, nboxes: int = 6) -> Config:
                   [3.0 * DEG] * 7, boxes)
 
 
-def config5(n: int = 512, nboxes: int = 128, seed: int = 5) -> Config:
-    """SURVEY 8d cfg 5: 14-DOF dual arm, 512^3 @ 0.01 m, tabletop + 128 boxes, eps 10 -> 1."""
-    res = 0.01
+def config5(n: int = 512, nboxes: int = 128, seed: int = 5, res: float = 0.01) -> Config:
+    """SURVEY 8d cfg 5: 14-DOF dual arm, 512^3 @ 0.01 m, tabletop + 128 boxes, eps 10 -> 1.
+    (n=64, res=0.08 gives the same scene at a size the oracle handles in tests.)"""
     size = n * res
     origin = (0.5 - 0.5 * size, -0.5 * size, 0.8 - 0.4 * size)
     rng = np.random.default_rng(seed)
@@ -314,7 +314,7 @@ def config5(n: int = 512, nboxes: int = 128, seed: int = 5) -> Config:
              (0.6, 0.3, 0.9), (0.5, -0.6, 0.95), (0.5, 0.6, 0.95)]
     boxes = [TABLETOP] + random_boxes(rng, nboxes, origin, (n, n, n), res, clear, 0.30, edge=(0.05, 0.25))
     grid = build_grid(origin, (n, n, n), res, 0.4, boxes)
-    p = PlanningParams([DEG] * 14, eps0=10.0, bfs_radius=0.02)
+    p = PlanningParams([DEG] * 14, eps0=10.0, bfs_radius=max(0.02, res))
     start = list(ARM7_START) + list(ARM7_START)
     start[7] = 0.0
     goal = _arm7_goal() + [ARM7_START[i] - ARM7_GOAL_CELLS[i] * DEG * (1 if i in (1, 3, 5) else -1) for i in range(7)]

@@ -200,3 +200,46 @@ def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused):
     if go["solved"]:
         q = s.extract_path(go["path"])
         assert np.array_equal(q[0], np.array(cfg.start))
+
+
+@pytest.fixture(scope="module")
+def dual_ctx():
+    """14-DOF dual arm (SURVEY cfg 5 robot) on a coarse grid: two kinematic chains from the root, 16 sphere trees,
+    85 checked link pairs including every inter-arm pair -- exercises the sphere-sphere slow path."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = scenes.config5(n=64, nboxes=12, res=0.08)
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg)
+    s.fused = False
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    return cfg, o, s
+
+
+def _dual_states(n, seed):
+    lim = scenes.ARM7_LIMITS + scenes.ARM7_LIMITS
+    return scenes.random_states(lim, n, seed)
+
+
+def test_dual_arm_state_validity_and_self_collision(dual_ctx):
+    cfg, o, s = dual_ctx
+    assert (s.model.nvars, s.model.ntrees, s.model.npairs) == (14, 16, 85)
+    Q = _dual_states(1500, 31)
+    # fold the left arm towards the right one so inter-arm pairs actually collide
+    Q[:500, 7] = -Q[:500, 0]
+    ok, lk = s.state_valid_batch(Q)
+    exp = [o.state_valid(q) for q in Q]
+    assert np.array_equal(ok.astype(bool), np.array([e[0] for e in exp]))
+    assert np.array_equal(lk, np.array([e[1] for e in exp]))
+    assert 0.02 < ok.mean() < 0.98
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+
+
+def test_dual_arm_expand_batch(dual_ctx):
+    cfg, o, s = dual_ctx
+    Q = np.vstack([np.array(cfg.start), _dual_states(60, 32)])
+    got = _compare_expand(o, s, Q)
+    assert got["flags"].shape[1] == 59          # 3 adaptive slots + 28 rows x 2
+    assert (got["flags"] & 1).sum() > 50
