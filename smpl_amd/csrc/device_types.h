@@ -49,12 +49,18 @@ struct SmplxNode {           // sphere-tree node; trees are stored post-order, r
 };
 
 struct alignas(16) SmplxModelDev {
-    int32_t njoints, nvars, ntrees, nnodes, npairs, nslots, nchain, pad0;
+    int32_t njoints, nvars, ntrees, nnodes, npairs, nslots, nchain, nroot;   // nroot: LDS root-position slots
     SmplxJoint joints[SMPLX_MAX_JOINTS];
     SmplxNode nodes[SMPLX_MAX_NODES];
     int32_t tree_first[SMPLX_MAX_TREES + 1];
     int32_t tree_joint[SMPLX_MAX_TREES];      // joint whose child link carries the tree
     int32_t pair_a[SMPLX_MAX_PAIRS], pair_b[SMPLX_MAX_PAIRS];  // tree indices, a before b in group order
+    // the same pairs regrouped for the kernels: for tree t (in depth-first order of its link) the partners that come
+    // EARLIER in that order are pair_other[pair_first[t] .. pair_first[t+1]); a tree that is somebody's earlier
+    // partner keeps its root position in LDS slot tree_root_slot[t] (-1 otherwise)
+    int32_t tree_root_slot[SMPLX_MAX_TREES];
+    int32_t pair_first[SMPLX_MAX_TREES + 1];
+    int32_t pair_other[SMPLX_MAX_PAIRS];
     // per planning variable
     double var_min[SMPLX_MAX_VARS], var_max[SMPLX_MAX_VARS];   // planning limits (continuous: -pi, pi)
     double var_min_norm[SMPLX_MAX_VARS];                        // normalize_angle(var_min)
@@ -100,9 +106,17 @@ struct SmplxGoalDev {
 static_assert(sizeof(SmplxModelDev) % 16 == 0 && sizeof(SmplxJoint) % 16 == 0 && sizeof(SmplxNode) % 16 == 0,
               "the model is copied to LDS in 16-byte pieces");
 
+// Packed copy of the USED part of the model, the form the kernels stage into LDS: a 64-byte header of int32
+// (counts, then byte offsets of the segments) followed by 16-byte aligned segments.
+enum { SMPLX_BH_NJOINTS = 0, SMPLX_BH_NVARS, SMPLX_BH_NTREES, SMPLX_BH_NNODES, SMPLX_BH_NPAIRS, SMPLX_BH_NSLOTS,
+       SMPLX_BH_NROOT, SMPLX_BH_BYTES, SMPLX_BH_OFF_JOINTS, SMPLX_BH_OFF_NODES, SMPLX_BH_OFF_INTS, SMPLX_BH_OFF_VARD,
+       SMPLX_BH_OFF_VARI, SMPLX_BH_WORDS = 16 };
+#define SMPLX_MAX_BLOB_BYTES (64 + SMPLX_MAX_JOINTS * 144 + SMPLX_MAX_NODES * 48 + 4096)
+
 // everything one query needs, resident in HBM
 struct SmplxSpaceDev {
     SmplxModelDev model;
+    alignas(16) unsigned char model_blob[SMPLX_MAX_BLOB_BYTES];
     SmplxGridDev grid;
     SmplxBfsDev bfs;
     SmplxActionsDev actions;

@@ -149,7 +149,7 @@ struct smplx_space {
     SmplxSpaceDev* d_space = nullptr;
     hipStream_t stream = nullptr;
     int N = 0, M = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, blob_bytes = 0;
     // BFS
     int32_t* d_bfs = nullptr;
     int32_t* d_queue[2] = {nullptr, nullptr};
@@ -242,7 +242,7 @@ int run_heuristic(smplx_space* s, const double* q, int n, int32_t* h, double* xy
     if (int e = s->b_h.reserve(n)) return e;
     if (int e = s->b_xyz.reserve((size_t)n * 3)) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * N, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_heuristic, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), 0, s->stream, s->d_space, s->b_q.p, n,
+    hipLaunchKernelGGL(k_heuristic, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->blob_bytes, s->stream, s->d_space, s->b_q.p, n,
                        s->b_h.p, s->b_xyz.p);
     HIP_TRY(hipGetLastError());
     if (h) HIP_TRY(hipMemcpyAsync(h, s->b_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
@@ -351,7 +351,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            d_counters, (const int*)nullptr);
         if (ev) (void)hipEventRecord(ev[2], stream);
     } else {
-        const size_t lm = smplx_lds_model_bytes();
+        const size_t lm = s->blob_bytes;
         hipLaunchKernelGGL(k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.work_count);
         hipLaunchKernelGGL(k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
@@ -667,11 +667,12 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     for (int i = 0; i < s->model.dev.nnodes; ++i)
         s->model.dev.nodes[i].thr = smplx::sphere_threshold(s->model.dev.nodes[i].r, params->padding, grid->res, grid->dmax_sqrd);
     s->wall_thr = smplx::wall_threshold(params->bfs_inflation_radius, grid->res, grid->dmax_sqrd);
-    s->lds_bytes = smplx_lds_bytes(s->model.dev.nnodes, s->model.dev.ntrees, s->model.dev.nslots);
-    if (s->lds_bytes > 160 * 1024) { delete s; return set_error(SMPLX_E_LIMIT, "model needs more LDS than a CU has"); }
-
     std::memset(&s->hs, 0, sizeof(s->hs));
     s->hs.model = s->model.dev;
+    s->blob_bytes = smplx::pack_model_blob(s->model.dev, s->hs.model_blob, sizeof(s->hs.model_blob));
+    if (s->blob_bytes == 0) { delete s; return set_error(SMPLX_E_LIMIT, "model does not fit the packed LDS image"); }
+    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots);
+    if (s->lds_bytes > 64 * 1024) { delete s; return set_error(SMPLX_E_LIMIT, "model needs more than 64 KB of LDS per block"); }
     s->hs.grid = grid->dev;
     s->hs.actions = A;
     s->hs.goal.type = SMPLX_GOAL_JOINT;

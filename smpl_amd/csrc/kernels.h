@@ -10,13 +10,10 @@
 #define SMPLX_STACK_BYTES 32
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
-// dynamic LDS bytes a collision kernel needs for a model
-static inline size_t smplx_lds_model_bytes(void) { return sizeof(SmplxModelDev); }
-static inline size_t smplx_lds_bytes(int nnodes, int ntrees, int nslots)
+// dynamic LDS bytes: the packed model, plus (collision kernels) per-thread scratch
+static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots)
 {
-    (void)nnodes;
-    return sizeof(SmplxModelDev) + (size_t)(3 * ntrees + 12 * nslots) * 8 * SMPLX_BLOCK +
-           (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
+    return blob_bytes + (size_t)(3 * nroot + 12 * nslots) * 8 * SMPLX_BLOCK + (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
 }
 
 extern "C" {

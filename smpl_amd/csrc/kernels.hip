@@ -27,6 +27,17 @@
 // small helpers
 // ---------------------------------------------------------------------------------------------
 
+// The compiled model as the kernels see it: counts plus pointers into the LDS copy of the packed model
+// (device_types.h SMPLX_BH_*).  Field names match SmplxModelDev so the device code reads the same either way.
+struct ModelLds {
+    int njoints, nvars, ntrees, nnodes, npairs, nslots, nroot;
+    const SmplxJoint* joints;
+    const SmplxNode* nodes;
+    const int *tree_first, *tree_joint, *tree_root_slot, *pair_first, *pair_other;
+    const double *var_min, *var_max, *var_min_norm, *var_k, *coord_delta;
+    const int *coord_vals, *var_type;
+};
+
 struct ThreadLds {
     const SmplxNode* nodes;   // shared: sphere trees
     double* d;                // per-thread doubles, SoA: d[e * BLOCK + tid]
@@ -140,16 +151,15 @@ __device__ __forceinline__ int grid_d2(const SmplxGridDev& g, const double p[3])
 
 // interpolated value of planning variable v on the edge start -> finish at parameter alpha
 // (robot_motion_collision_model.h:221-247 diffs, 297-320 interpolate)
-__device__ __forceinline__ double edge_diff(const SmplxModelDev* __restrict__ M, int v, double sv, double fv)
+__device__ __forceinline__ double edge_diff(const ModelLds* __restrict__ M, int v, double sv, double fv)
 {
     return (M->var_type[v] == SMPLX_JT_CONTINUOUS) ? smplx_shortest_angle_diff(fv, sv) : fv - sv;
 }
 
 // sphere tree vs voxel grid for the tree on the current link (collision_operations.h:105-164).
-// Returns false at the first colliding leaf.  The root position is left in LDS for the
-// sphere-sphere pass.
-__device__ __forceinline__ bool check_tree(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
-                                           int t, const double T[12], int& lookups)
+// Returns false at the first colliding leaf.  The root position comes back for the sphere-sphere tests.
+__device__ __forceinline__ bool check_tree(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                           int t, const double T[12], int& lookups, double root_p[3])
 {
     const int root = M->tree_first[t + 1] - 1;
     int sp = 0;
@@ -159,11 +169,7 @@ __device__ __forceinline__ bool check_tree(const SmplxModelDev* __restrict__ M, 
         double c[3] = {nd.c[0], nd.c[1], nd.c[2]};
         double p[3];
         xform(T, c, p);
-        if (node == root) {
-            lds_d(L, L.root_base + 3 * t + 0) = p[0];
-            lds_d(L, L.root_base + 3 * t + 1) = p[1];
-            lds_d(L, L.root_base + 3 * t + 2) = p[2];
-        }
+        if (node == root) { root_p[0] = p[0]; root_p[1] = p[1]; root_p[2] = p[2]; }
         ++lookups;
         const int d2 = grid_d2(g, p);
         if (d2 < nd.thr) {              // CheckSphereCollision fails (collision_operations.h:67-77)
@@ -187,7 +193,7 @@ struct EdgeRef {
     double alpha;
 };
 
-__device__ __forceinline__ double config_var(const SmplxModelDev* __restrict__ M, const EdgeRef& e, int v)
+__device__ __forceinline__ double config_var(const ModelLds* __restrict__ M, const EdgeRef& e, int v)
 {
     const double sv = e.start[v];
     if (e.alpha == 0.0) return sv;      // start + 0*diff == start exactly
@@ -196,7 +202,7 @@ __device__ __forceinline__ double config_var(const SmplxModelDev* __restrict__ M
 }
 
 // link transforms of two trees' links for one configuration (slow path of the sphere-sphere pass)
-__device__ __noinline__ void fk_two_links(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+__device__ __noinline__ void fk_two_links(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
                                           int ja, int jb, double Ta[12], double Tb[12])
 {
     double T[12];
@@ -234,7 +240,7 @@ __device__ __noinline__ void fk_two_links(const SmplxModelDev* __restrict__ M, c
 }
 
 // sphere tree vs sphere tree (self_collision_model.cpp:1093-1218); false = collision
-__device__ __noinline__ bool check_pair_full(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+__device__ __noinline__ bool check_pair_full(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
                                              int ta, int tb)
 {
     double Ta[12], Tb[12];
@@ -278,12 +284,15 @@ __device__ __noinline__ bool check_pair_full(const SmplxModelDev* __restrict__ M
 // CollisionSpace::isStateValid for one configuration (collision_space.cpp:532-536 ->
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
-__device__ __forceinline__ bool config_valid(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+__device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                              const EdgeRef& e, int& lookups)
 {
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = 0.0;
+    bool pair_hit = false, recheck_all = false;
+    unsigned long long pending = 0;   // queued (earlier tree, later tree) pairs, 16 bits each
+    int npending = 0;
     const int nj = M->njoints;
     for (int j = 0; j < nj; ++j) {
         const SmplxJoint* jt = &M->joints[j];
@@ -305,29 +314,66 @@ __device__ __forceinline__ bool config_valid(const SmplxModelDev* __restrict__ M
             for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * jt->save_slot + i) = T[i];
         }
         if (jt->tree >= 0) {
-            if (!check_tree(M, L, g, jt->tree, T, lookups)) return false;
+            const int t = jt->tree;
+            double rp[3];
+            if (!check_tree(M, L, g, t, T, lookups, rp)) return false;   // voxel collision: the reference stops here too
+            const int slot = M->tree_root_slot[t];
+            if (slot >= 0) {
+                lds_d(L, L.root_base + 3 * slot + 0) = rp[0];
+                lds_d(L, L.root_base + 3 * slot + 1) = rp[1];
+                lds_d(L, L.root_base + 3 * slot + 2) = rp[2];
+            }
+            // checked link pairs whose later tree is t: root-vs-root now (self_collision_model.cpp:1111-1123);
+            // anything the roots do not settle is queued and resolved after the chain (the slow path reuses the
+            // transform slots).  A hit does not stop the voxel pass: the reference runs ALL voxel checks before
+            // the first pair (self_collision_model.cpp:418-421), so lookup tallies stay identical.
+            const SmplxNode& B = L.nodes[M->tree_first[t + 1] - 1];
+            for (int k = M->pair_first[t]; k < M->pair_first[t + 1]; ++k) {
+                const int ta = M->pair_other[k];
+                const int sa = M->tree_root_slot[ta];
+                const SmplxNode& A = L.nodes[M->tree_first[ta + 1] - 1];
+                // pairs are stored (group-earlier, group-later); the subtraction order follows that
+                const bool a_first = ta < t;
+                const double ax = lds_d(L, L.root_base + 3 * sa + 0), ay = lds_d(L, L.root_base + 3 * sa + 1),
+                             az = lds_d(L, L.root_base + 3 * sa + 2);
+                const double dx = a_first ? rp[0] - ax : ax - rp[0];
+                const double dy = a_first ? rp[1] - ay : ay - rp[1];
+                const double dz = a_first ? rp[2] - az : az - rp[2];
+                const double cd2 = (dx * dx + dy * dy) + dz * dz;
+                const double rr = a_first ? A.r + B.r : B.r + A.r;
+                if (cd2 > rr * rr) continue;
+                if (A.left < 0 && B.left < 0) { pair_hit = true; continue; }
+                // queue (ta, t): 8 bits each, up to 4 pairs in the 64-bit word; more -> recheck everything
+                if (npending < 4) {
+                    pending = (pending << 16) | (unsigned long long)((ta << 8) | t);
+                    ++npending;
+                } else {
+                    recheck_all = true;
+                }
+            }
         }
     }
-    const int np = M->npairs;
-    for (int k = 0; k < np; ++k) {
-        const int ta = M->pair_a[k], tb = M->pair_b[k];
-        const SmplxNode& A = L.nodes[M->tree_first[ta + 1] - 1];
-        const SmplxNode& B = L.nodes[M->tree_first[tb + 1] - 1];
-        const double dx = lds_d(L, L.root_base + 3 * tb + 0) - lds_d(L, L.root_base + 3 * ta + 0);
-        const double dy = lds_d(L, L.root_base + 3 * tb + 1) - lds_d(L, L.root_base + 3 * ta + 1);
-        const double dz = lds_d(L, L.root_base + 3 * tb + 2) - lds_d(L, L.root_base + 3 * ta + 2);
-        const double cd2 = (dx * dx + dy * dy) + dz * dz;
-        const double rr = A.r + B.r;
-        if (cd2 > rr * rr) continue;
-        if (A.left < 0 && B.left < 0) return false;
-        if (!check_pair_full(M, L, e, ta, tb)) return false;
+    if (recheck_all) {
+        for (int t = 0; t < M->ntrees && !pair_hit; ++t)
+            for (int k = M->pair_first[t]; k < M->pair_first[t + 1] && !pair_hit; ++k) {
+                const int ta = M->pair_other[k];
+                const int a = ta < t ? ta : t, b = ta < t ? t : ta;
+                if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
+            }
+    } else {
+        for (int i = 0; i < npending && !pair_hit; ++i) {
+            const int code = (int)((pending >> (16 * i)) & 0xFFFF);
+            const int ta = code >> 8, t = code & 0xFF;
+            const int a = ta < t ? ta : t, b = ta < t ? t : ta;
+            if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
+        }
     }
-    return true;
+    return !pair_hit;
 }
 
 // CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
 // (the start configuration), whose result the caller already has.
-__device__ __forceinline__ bool edge_valid(const SmplxModelDev* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+__device__ __forceinline__ bool edge_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                            const double* __restrict__ start, const double* __restrict__ finish,
                                            bool start_known, bool start_valid, int& lookups, int& waypoints)
 {
@@ -372,7 +418,7 @@ __device__ __forceinline__ bool edge_valid(const SmplxModelDev* __restrict__ M, 
 
 // planning-link position ("KDL" FK restated as the same serial chain; kdl_robot_model.cpp:400-423,
 // continuous joints normalised first :191-198)
-__device__ __forceinline__ void planning_fk(const SmplxModelDev* __restrict__ M, const double* __restrict__ q, double p[3])
+__device__ __forceinline__ void planning_fk(const ModelLds* __restrict__ M, const double* __restrict__ q, double p[3])
 {
     double T[12];
 #pragma unroll
@@ -427,7 +473,7 @@ __device__ __forceinline__ int bfs_cost_to_goal(const SmplxBfsDev& b, const int 
 }
 
 // KDLRobotModel::checkJointLimits (kdl_robot_model.cpp:173-189, 210-235)
-__device__ __forceinline__ bool check_joint_limits(const SmplxModelDev* __restrict__ M, const double* __restrict__ q)
+__device__ __forceinline__ bool check_joint_limits(const ModelLds* __restrict__ M, const double* __restrict__ q)
 {
     const int nv = M->nvars;
     for (int v = 0; v < nv; ++v) {
@@ -442,7 +488,7 @@ __device__ __forceinline__ bool check_joint_limits(const SmplxModelDev* __restri
 }
 
 // ManipLattice::stateToCoord for one variable (manip_lattice.cpp:1263-1289)
-__device__ __forceinline__ int var_to_coord(const SmplxModelDev* __restrict__ M, int v, double x)
+__device__ __forceinline__ int var_to_coord(const ModelLds* __restrict__ M, int v, double x)
 {
     const double delta = M->coord_delta[v];
     const int ty = M->var_type[v];
@@ -456,68 +502,70 @@ __device__ __forceinline__ int var_to_coord(const SmplxModelDev* __restrict__ M,
     return (int)(((x - M->var_min[v]) / delta) + 0.5);
 }
 
-// Cooperative copy of the USED part of the compiled model into LDS (header + joints, sphere-tree
-// nodes, the small per-tree / per-pair / per-variable tables) in 16-byte pieces, all loads of a
-// thread issued before the first store.  Every later read of the model is a uniform-address LDS
-// broadcast instead of a dependent global load.
-__device__ __forceinline__ const SmplxModelDev* stage_model(const SmplxModelDev* __restrict__ Mg, unsigned char* smem)
+// Cooperative copy of the packed model (a few KB) into LDS in 16-byte pieces, all loads of a thread issued before
+// its first store; every later read of the model is a uniform-address LDS broadcast instead of a dependent
+// global load.  Returns the view.
+__device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict__ S, unsigned char* smem)
 {
     typedef double __attribute__((ext_vector_type(2))) d2_t;
-    const d2_t* src = reinterpret_cast<const d2_t*>(Mg);
+    const int* hdr = reinterpret_cast<const int*>(S->model_blob);
+    const d2_t* src = reinterpret_cast<const d2_t*>(S->model_blob);
     d2_t* dst = reinterpret_cast<d2_t*>(smem);
-    const int nj = Mg->njoints, nn = Mg->nnodes;
-    const int seg0 = (int)((offsetof(SmplxModelDev, joints) + (size_t)nj * sizeof(SmplxJoint)) / 16);
-    const int off1 = (int)(offsetof(SmplxModelDev, nodes) / 16);
-    const int seg1 = (int)((size_t)nn * sizeof(SmplxNode) / 16);
-    const int off2 = (int)(offsetof(SmplxModelDev, tree_first) / 16);
-    const int seg2 = (int)(sizeof(SmplxModelDev) / 16) - off2;
-    const int total = seg0 + seg1 + seg2;
+    const int total = hdr[SMPLX_BH_BYTES] / 16;
     d2_t v[4];
-    int idx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = threadIdx.x + k * BLOCK;
-        int j = -1;
-        if (i < seg0) j = i;
-        else if (i < seg0 + seg1) j = off1 + (i - seg0);
-        else if (i < total) j = off2 + (i - seg0 - seg1);
-        idx[k] = j;
-        if (j >= 0) v[k] = src[j];
+        if (i < total) v[k] = src[i];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (idx[k] >= 0) dst[idx[k]] = v[k];
-    for (int i = threadIdx.x + 4 * BLOCK; i < total; i += BLOCK) {   // models larger than 8 KB
-        int j;
-        if (i < seg0) j = i;
-        else if (i < seg0 + seg1) j = off1 + (i - seg0);
-        else j = off2 + (i - seg0 - seg1);
-        dst[j] = src[j];
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + k * BLOCK;
+        if (i < total) dst[i] = v[k];
     }
-    return reinterpret_cast<const SmplxModelDev*>(smem);
+    for (int i = threadIdx.x + 4 * BLOCK; i < total; i += BLOCK) dst[i] = src[i];
+    ModelLds M;
+    M.njoints = hdr[SMPLX_BH_NJOINTS]; M.nvars = hdr[SMPLX_BH_NVARS]; M.ntrees = hdr[SMPLX_BH_NTREES];
+    M.nnodes = hdr[SMPLX_BH_NNODES]; M.npairs = hdr[SMPLX_BH_NPAIRS]; M.nslots = hdr[SMPLX_BH_NSLOTS];
+    M.nroot = hdr[SMPLX_BH_NROOT];
+    M.joints = reinterpret_cast<const SmplxJoint*>(smem + hdr[SMPLX_BH_OFF_JOINTS]);
+    M.nodes = reinterpret_cast<const SmplxNode*>(smem + hdr[SMPLX_BH_OFF_NODES]);
+    const int* ip = reinterpret_cast<const int*>(smem + hdr[SMPLX_BH_OFF_INTS]);
+    M.tree_first = ip; ip += M.ntrees + 1;
+    M.tree_joint = ip; ip += M.ntrees;
+    M.tree_root_slot = ip; ip += M.ntrees;
+    M.pair_first = ip; ip += M.ntrees + 1;
+    M.pair_other = ip;
+    const double* dp = reinterpret_cast<const double*>(smem + hdr[SMPLX_BH_OFF_VARD]);
+    M.var_min = dp; M.var_max = dp + M.nvars; M.var_min_norm = dp + 2 * M.nvars; M.var_k = dp + 3 * M.nvars;
+    M.coord_delta = dp + 4 * M.nvars;
+    const int* vp = reinterpret_cast<const int*>(smem + hdr[SMPLX_BH_OFF_VARI]);
+    M.coord_vals = vp; M.var_type = vp + M.nvars;
+    return M;
 }
 
-__device__ __forceinline__ ThreadLds setup_lds(const SmplxModelDev* __restrict__ Mg, unsigned char* smem,
-                                               const SmplxModelDev** M_lds)
+// model + per-thread scratch (root-position slots, saved transforms, DFS stack)
+__device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__ S, unsigned char* smem, ModelLds* Mv)
 {
     ThreadLds L;
-    const SmplxModelDev* Ml = stage_model(Mg, smem);
-    *M_lds = Ml;
-    L.nodes = Ml->nodes;
-    L.d = reinterpret_cast<double*>(smem + sizeof(SmplxModelDev));
+    *Mv = stage_model(S, smem);
+    const int* hdr = reinterpret_cast<const int*>(S->model_blob);
+    L.nodes = Mv->nodes;
+    L.d = reinterpret_cast<double*>(smem + hdr[SMPLX_BH_BYTES]);
     L.root_base = 0;
-    L.slot_base = 3 * Mg->ntrees;
-    const int nd = 3 * Mg->ntrees + 12 * Mg->nslots;
+    L.slot_base = 3 * Mv->nroot;
+    const int nd = 3 * Mv->nroot + 12 * Mv->nslots;
     L.stk = reinterpret_cast<unsigned char*>(L.d + (size_t)nd * BLOCK);
     __syncthreads();
     return L;
 }
 
 // kernels that only need the model (no per-thread scratch)
-__device__ __forceinline__ const SmplxModelDev* setup_model_only(const SmplxModelDev* __restrict__ Mg, unsigned char* smem)
+__device__ __forceinline__ ModelLds setup_model_only(const SmplxSpaceDev* __restrict__ S, unsigned char* smem)
 {
-    const SmplxModelDev* Ml = stage_model(Mg, smem);
+    ModelLds M = stage_model(S, smem);
     __syncthreads();
-    return Ml;
+    return M;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,8 +577,9 @@ k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
              double* __restrict__ goal_dist, unsigned char* __restrict__ parent_valid, int* __restrict__ parent_lookups)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M;
-    ThreadLds L = setup_lds(&S->model, smem, &M);
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv);
+    const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const SmplxBfsDev bfs = S->bfs;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -602,9 +651,10 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
     // second pass after the pipeline (deferred_count != nullptr): nothing to do in the common case
     const bool only_deferred = deferred_count != nullptr;
     if (only_deferred && deferred_count[0] == 0) return;
-    const SmplxModelDev* M;
+    ModelLds Mv;
     const SmplxActionsDev& A = S->actions;
-    ThreadLds L = setup_lds(&S->model, smem, &M);
+    ThreadLds L = setup_lds(S, smem, &Mv);
+    const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const SmplxBfsDev bfs = S->bfs;
     const int nprims = A.nprims;
@@ -723,7 +773,8 @@ k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, c
             double* __restrict__ goal_dist, int* __restrict__ work_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = setup_model_only(&S->model, smem);
+    const ModelLds Mv = setup_model_only(S, smem);
+    const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const SmplxBfsDev bfs = S->bfs;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -745,7 +796,8 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
              unsigned int* __restrict__ work, int* __restrict__ work_count, int capacity)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = setup_model_only(&S->model, smem);
+    const ModelLds Mv = setup_model_only(S, smem);
+    const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const int nprims = A.nprims;
     const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -865,8 +917,9 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     }
     const long long total = (long long)B + pre[SMPLX_WORK_SHARDS];
     if ((long long)blockIdx.x * BLOCK >= total) return;   // whole block idle: skip staging the model
-    const SmplxModelDev* M;
-    ThreadLds L = setup_lds(&S->model, smem, &M);
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv);
+    const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const int nprims = S->actions.nprims;
     const int nv = M->nvars;
@@ -910,7 +963,8 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               unsigned long long* __restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M = setup_model_only(&S->model, smem);
+    const ModelLds Mv = setup_model_only(S, smem);
+    const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
     const SmplxBfsDev bfs = S->bfs;
@@ -975,8 +1029,9 @@ k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq,
              unsigned char* __restrict__ out, int* __restrict__ out_lookups, int* __restrict__ out_waypoints)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M;
-    ThreadLds L = setup_lds(&S->model, smem, &M);
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv);
+    const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     int lk = 0, W = 0;
@@ -992,8 +1047,9 @@ k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               int* __restrict__ out_lookups)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M;
-    ThreadLds L = setup_lds(&S->model, smem, &M);
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv);
+    const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     EdgeRef e;
@@ -1009,9 +1065,11 @@ extern "C" __global__ void __launch_bounds__(BLOCK)
 k_heuristic(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, int* __restrict__ out_h,
             double* __restrict__ out_xyz)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const ModelLds Mv = setup_model_only(S, smem);
+    const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const SmplxModelDev* M = &S->model;
     double p[3];
     planning_fk(M, Q + (size_t)i * M->nvars, p);
     int c[3];
@@ -1025,8 +1083,9 @@ extern "C" __global__ void __launch_bounds__(BLOCK)
 k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, double* __restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SmplxModelDev* M;
-    ThreadLds L = setup_lds(&S->model, smem, &M);
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv);
+    const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const double* q = Q + (size_t)i * M->nvars;

@@ -466,6 +466,26 @@ bool compile_robot_text(const char* text, HostModel& m)
         }
     }
 
+    // kernel-side regrouping of the checked pairs by the partner that comes later in depth-first link order
+    {
+        std::vector<std::vector<int>> earlier(D.ntrees);
+        std::vector<char> leads(D.ntrees, 0);
+        for (int k = 0; k < D.npairs; ++k) {
+            int a = D.pair_a[k], b = D.pair_b[k];
+            if (D.tree_joint[a] > D.tree_joint[b]) std::swap(a, b);
+            earlier[b].push_back(a);
+            leads[a] = 1;
+        }
+        D.nroot = 0;
+        int n = 0;
+        for (int t = 0; t < D.ntrees; ++t) {
+            D.tree_root_slot[t] = leads[t] ? D.nroot++ : -1;
+            D.pair_first[t] = n;
+            for (int a : earlier[t]) D.pair_other[n++] = a;
+        }
+        D.pair_first[D.ntrees] = n;
+    }
+
     // chain to the planning link
     int l = link_index(m.planning_link);
     if (l < 0) return fail("planning link unknown: " + m.planning_link);
@@ -537,6 +557,42 @@ bool load_mprim_text(const char* text, const double* resolutions, int nvars, Hos
         }
     }
     return true;
+}
+
+size_t pack_model_blob(const SmplxModelDev& m, unsigned char* out, size_t cap)
+{
+    auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    int32_t hdr[SMPLX_BH_WORDS] = {0};
+    size_t off = 64;
+    const size_t o_j = off; off = up16(off + (size_t)m.njoints * sizeof(SmplxJoint));
+    const size_t o_n = off; off = up16(off + (size_t)m.nnodes * sizeof(SmplxNode));
+    const size_t n_ints = (size_t)(m.ntrees + 1) + m.ntrees + m.ntrees + (m.ntrees + 1) + m.npairs;
+    const size_t o_i = off; off = up16(off + n_ints * 4);
+    const size_t o_d = off; off = up16(off + (size_t)m.nvars * 5 * 8);
+    const size_t o_v = off; off = up16(off + (size_t)m.nvars * 2 * 4);
+    if (off > cap) return 0;
+    hdr[SMPLX_BH_NJOINTS] = m.njoints; hdr[SMPLX_BH_NVARS] = m.nvars; hdr[SMPLX_BH_NTREES] = m.ntrees;
+    hdr[SMPLX_BH_NNODES] = m.nnodes; hdr[SMPLX_BH_NPAIRS] = m.npairs; hdr[SMPLX_BH_NSLOTS] = m.nslots;
+    hdr[SMPLX_BH_NROOT] = m.nroot; hdr[SMPLX_BH_BYTES] = (int32_t)off;
+    hdr[SMPLX_BH_OFF_JOINTS] = (int32_t)o_j; hdr[SMPLX_BH_OFF_NODES] = (int32_t)o_n; hdr[SMPLX_BH_OFF_INTS] = (int32_t)o_i;
+    hdr[SMPLX_BH_OFF_VARD] = (int32_t)o_d; hdr[SMPLX_BH_OFF_VARI] = (int32_t)o_v;
+    std::memset(out, 0, off);
+    std::memcpy(out, hdr, sizeof(hdr));
+    std::memcpy(out + o_j, m.joints, (size_t)m.njoints * sizeof(SmplxJoint));
+    std::memcpy(out + o_n, m.nodes, (size_t)m.nnodes * sizeof(SmplxNode));
+    int32_t* ip = (int32_t*)(out + o_i);
+    std::memcpy(ip, m.tree_first, (m.ntrees + 1) * 4); ip += m.ntrees + 1;
+    std::memcpy(ip, m.tree_joint, m.ntrees * 4); ip += m.ntrees;
+    std::memcpy(ip, m.tree_root_slot, m.ntrees * 4); ip += m.ntrees;
+    std::memcpy(ip, m.pair_first, (m.ntrees + 1) * 4); ip += m.ntrees + 1;
+    std::memcpy(ip, m.pair_other, m.npairs * 4);
+    double* dp = (double*)(out + o_d);
+    const double* srcs[5] = {m.var_min, m.var_max, m.var_min_norm, m.var_k, m.coord_delta};
+    for (int a = 0; a < 5; ++a) std::memcpy(dp + (size_t)a * m.nvars, srcs[a], (size_t)m.nvars * 8);
+    int32_t* vp = (int32_t*)(out + o_v);
+    std::memcpy(vp, m.coord_vals, (size_t)m.nvars * 4);
+    std::memcpy(vp + m.nvars, m.var_type, (size_t)m.nvars * 4);
+    return off;
 }
 
 void fill_discretization(SmplxModelDev& m, const double* resolutions)

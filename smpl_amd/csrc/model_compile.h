@@ -41,6 +41,9 @@ struct HostActions {
 // (cols == nvars + 2: deltas, group, weight)
 bool load_mprim_text(const char* text, const double* resolutions, int nvars, HostActions& a);
 
+// packed model for LDS staging (device_types.h SMPLX_BH_*); returns the byte count, 0 if it does not fit cap
+size_t pack_model_blob(const SmplxModelDev& m, unsigned char* out, size_t cap);
+
 // ManipLattice::init discretisation (manip_lattice.cpp:125-139)
 void fill_discretization(SmplxModelDev& m, const double* resolutions);
 
