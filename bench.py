@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--planner-expansions", type=int, default=40000)
+    ap.add_argument("--multi-queries", type=int, default=16, help="queries interleaved on one GPU in the planner leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     args = ap.parse_args()
@@ -221,6 +222,32 @@ def main():
                            "expansions_equal": bool(ro["expansions"] == rg["expansions"]),
                            "expanded_ids_equal": bool(np.array_equal(ro["expansion_log"], rg["expansion_log"])),
                            "path_equal": bool(np.array_equal(ro["path"], rg["path"]))}}
+
+    if rank == 0 and world == 1 and not args.no_planner and args.multi_queries > 1:
+        # batched-query planner leg (BASELINE config 4 shape on one GPU): Q independent queries interleaved by one
+        # host thread; aggregate committed expansions / wall time.  Parity is checked on the first query when the
+        # CPU leg ran, and in tests/test_gpu_parity.py for all of them.
+        nq, nb = args.multi_queries, args.planner_expansions
+        spaces = []
+        for qi in range(nq):
+            g = [a + c * scenes.DEG for a, c in zip(cfg.goal, rank_goal_shift(qi))]
+            sp = capi.Space.from_config(cfg, batch_states=args.batch)
+            okq, _ = sp.state_valid_batch(np.array([g]))
+            sp.set_goal_joint(g if okq[0] else cfg.goal, cfg.goal_tol)
+            sp.set_start(cfg.start)
+            spaces.append(sp)
+        res, wall = capi.Space.plan_multi(spaces, p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+        tot = sum(r["expansions"] for r in res)
+        out["planner_multi"] = {
+            "queries": nq, "expansion_bound_per_query": nb, "wall_seconds": round(wall, 4),
+            "states_expanded_per_s": round(tot / wall, 1), "expansions_total": tot,
+            "solved": int(sum(r["solved"] for r in res)),
+            "gpu_succ_evals_total": int(sum(r["gpu_succ_evals"] for r in res)),
+            "committed_succ_evals": int(sum(r["committed_succ_evals"] for r in res)),
+            "gpu_batches": int(sum(r["gpu_batches"] for r in res)),
+            "first_query_matches_single": bool("planner" in out and res[0]["cost"] == out["planner"]["path_cost"]
+                                               and res[0]["expansions"] == out["planner"]["expansions"])}
+        del spaces
 
     if rank == 0:
         print(json.dumps(out))

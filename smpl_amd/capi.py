@@ -29,7 +29,7 @@ SYMBOLS = [
     "smplx_expand_work_bytes", "smplx_expand_batch_device", "smplx_set_start", "smplx_start_id", "smplx_goal_id",
     "smplx_get_succs", "smplx_hint_frontier", "smplx_get_goal_heuristic", "smplx_num_states", "smplx_get_state",
     "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_profile_begin",
-    "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read",
+    "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read", "smplx_plan_multi",
 ]
 
 
@@ -338,6 +338,28 @@ class Space:
         out["path"] = ids[:S.path_len].copy()
         out["expansion_log"] = log
         return out
+
+    @staticmethod
+    def plan_multi(spaces, eps0, eps_final, eps_delta, improve=True, bounded=False, max_init=0, max_rep=0, cap=4096):
+        """Interleaved ARA* over independent queries on one GPU (smplx_plan_multi)."""
+        nq = len(spaces)
+        P = SearchParams(eps0, eps_final, eps_delta, int(improve), int(bounded), max_init, max_rep)
+        St = (SearchStats * nq)()
+        H = (C.c_void_p * nq)(*[sp.h for sp in spaces])
+        ids = np.zeros((nq, cap), np.int32)
+        wall = C.c_double()
+        _chk(lib().smplx_plan_multi(H, nq, C.byref(P), _p(ids, _ip), cap, St, C.byref(wall)))
+        out = []
+        for q, sp in enumerate(spaces):
+            d = {f: getattr(St[q], f) for f, _ in SearchStats._fields_}
+            d["path"] = ids[q, :St[q].path_len].copy()
+            n = lib().smplx_expansion_log_size(sp.h)
+            log = np.zeros(n, np.int32)
+            if n:
+                _chk(lib().smplx_expansion_log(sp.h, _p(log, _ip)))
+            d["expansion_log"] = log
+            out.append(d)
+        return out, wall.value
 
     def extract_path(self, ids):
         ids = np.ascontiguousarray(ids, np.int32); q = np.zeros((ids.shape[0], self.N))

@@ -186,6 +186,9 @@ struct smplx_space {
     std::vector<int32_t> done_cnt;
     std::vector<int32_t> done_succ, done_cost;
     std::vector<int32_t> hint;
+    // a frontier batch in flight (issued on `stream`, completion signalled by `batch_done`)
+    std::vector<int32_t> inflight;
+    hipEvent_t batch_done = nullptr;
     // stats
     int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0;
     std::vector<int32_t> eval_count;    // per id: evaluated (active) primitives, for committed_evals
@@ -427,11 +430,14 @@ void reset_lattice(smplx_space* s)
 }
 
 // evaluate the successors of `id` plus hinted frontier states in one frontier batch
-int run_batch(smplx_space* s, int id)
+// enqueue one frontier batch (state `id` plus hinted frontier states) on the space's stream: upload, the
+// expansion pipeline, download, completion event.  Returns without waiting.
+int issue_batch(smplx_space* s, int id)
 {
     const int N = s->N, M = s->M;
     const int cap = s->params.batch_states > 0 ? s->params.batch_states : 4096;
-    std::vector<int32_t> batch;
+    std::vector<int32_t>& batch = s->inflight;
+    batch.clear();
     batch.push_back(id);
     s->cache_off[id] = -2;   // mark as "in this batch"
     for (int32_t hId : s->hint) {
@@ -459,8 +465,17 @@ int run_batch(smplx_space* s, int id)
     HIP_TRY(hipMemcpyAsync(s->p_h.p, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(s->p_coord.p, s->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(s->p_sq.p, s->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipEventRecord(s->batch_done, s->stream));
     ++s->gpu_batches;
+    return SMPLX_OK;
+}
+
+// the batch in flight has completed: turn its dense outputs into cached successor records
+int collect_batch(smplx_space* s)
+{
+    const int N = s->N, M = s->M;
+    const std::vector<int32_t>& batch = s->inflight;
+    const int B = (int)batch.size();
     for (int i = 0; i < B; ++i) {
         const int sid = batch[i];
         s->cache_off[sid] = (int64_t)s->recs.size();
@@ -482,7 +497,15 @@ int run_batch(smplx_space* s, int id)
         s->cache_cnt[sid] = cnt;
         s->eval_count[sid] = evals;
     }
+    s->inflight.clear();
     return SMPLX_OK;
+}
+
+int run_batch(smplx_space* s, int id)
+{
+    if (int e = issue_batch(s, id)) return e;
+    HIP_TRY(hipEventSynchronize(s->batch_done));
+    return collect_batch(s);
 }
 
 // GetSuccs (manip_lattice.cpp:219-313): ids are assigned here, in the caller's sequential order
@@ -492,7 +515,7 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
     if (id < 0 || id >= (int)s->cache_off.size()) return set_error(SMPLX_E_STATE, "unknown state id");
     if (s->done_off[id] < 0) {
         if (s->cache_off[id] < 0) {
-            ++s->cache_misses;
+            ++s->cache_misses;   // plain GetSuccs callers (the unchanged ARA* of smpl): synchronous batch
             if (int e = run_batch(s, id)) return e;
         } else {
             ++s->cache_hits;
@@ -671,8 +694,8 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->hs.model = s->model.dev;
     s->blob_bytes = smplx::pack_model_blob(s->model.dev, s->hs.model_blob, sizeof(s->hs.model_blob));
     if (s->blob_bytes == 0) { delete s; return set_error(SMPLX_E_LIMIT, "model does not fit the packed LDS image"); }
-    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots);
-    if (s->lds_bytes > 64 * 1024) { delete s; return set_error(SMPLX_E_LIMIT, "model needs more than 64 KB of LDS per block"); }
+    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars);
+    if (s->lds_bytes > 160 * 1024) { delete s; return set_error(SMPLX_E_LIMIT, "model needs more LDS per block than a CU has (160 KB)"); }
     s->hs.grid = grid->dev;
     s->hs.actions = A;
     s->hs.goal.type = SMPLX_GOAL_JOINT;
@@ -684,6 +707,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     };
     hipError_t e;
     if ((e = hipStreamCreate(&s->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&s->batch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
     const int dx = grid->n[0] + 2, dy = grid->n[1] + 2, dz = grid->n[2] + 2;
     s->bfs_total = (int64_t)dx * dy * dz;
@@ -709,6 +733,7 @@ void smplx_space_destroy(smplx_space* s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
+    if (s->batch_done) (void)hipEventDestroy(s->batch_done);
     if (s->d_space) (void)hipFree(s->d_space);
     if (s->d_bfs) (void)hipFree(s->d_bfs);
     if (s->d_queue[0]) (void)hipFree(s->d_queue[0]);
@@ -1154,13 +1179,7 @@ struct Search {
     {
         const int32_t *succs, *costs;
         int n = 0;
-        if (sp->done_off[sid] < 0 && sp->cache_off[sid] < 0 && sid != 0) {
-            // about to miss: let the top of OPEN ride along in the same frontier batch
-            const int cap = sp->params.batch_states > 0 ? sp->params.batch_states : 4096;
-            sp->hint.clear();
-            for (size_t i = 1; i < heap.size() && (int)sp->hint.size() < cap - 1; ++i) sp->hint.push_back(heap[i]);
-        }
-        error = get_succs(sp, sid, &succs, &costs, &n);
+        error = get_succs(sp, sid, &succs, &costs, &n);   // served from the cache: improve_path checked ready(sid)
         if (error) return;
         // copies: get_succs of a later state may grow the committed arrays
         std::vector<int32_t> ss(succs, succs + n), cc(costs, costs + n);
@@ -1183,12 +1202,27 @@ struct Search {
             }
         }
     }
-    int improve_path(int& elapsed)   // arastar.cpp:486-527
+    // states whose successors are already on the host (cached or committed); the goal never expands
+    bool ready(int sid) const { return sid == 0 || sp->done_off[sid] >= 0 || sp->cache_off[sid] >= 0; }
+
+    enum { R_DONE = 0, R_YIELD = 100 };
+    int improve_path(int& elapsed)   // arastar.cpp:486-527; returns R_YIELD when a frontier batch was issued
     {
         while (!heap_empty()) {
             const int m = heap[1];
             if (st[m].f >= st[goal_id].f || m == goal_id) return 0;
             if (timed_out(elapsed)) return 4;
+            if (!ready(m)) {
+                // cache miss: the state and the top of OPEN go to the GPU as one frontier batch; the search
+                // resumes from exactly this point when the batch has landed (nothing has been popped yet)
+                const int cap = sp->params.batch_states > 0 ? sp->params.batch_states : 4096;
+                sp->hint.clear();
+                for (size_t i = 2; i < heap.size() && (int)sp->hint.size() < cap - 1; ++i) sp->hint.push_back(heap[i]);
+                ++sp->cache_misses;
+                error = issue_batch(sp, m);
+                if (error) return 99;
+                return R_YIELD;
+            }
             pop();
             st[m].iteration_closed = (unsigned short)iteration;
             st[m].eg = st[m].g;
@@ -1199,57 +1233,69 @@ struct Search {
         }
         return 5;
     }
-    int replan(std::vector<int>& solution, int& cost)   // arastar.cpp:107-215, always from scratch
+
+    // arastar.cpp:107-215 (always from scratch) as a resumable state machine: resume() runs until the search
+    // finishes (R_DONE) or a frontier batch is in flight (R_YIELD)
+    int phase = 0, num = 0, err = 0, solved = 0, cost = 0;
+    std::vector<int> solution;
+    int resume()
     {
-        heap.assign(1, 0);
-        incons.clear();
-        ++call_number;
-        reinit(start_id);
-        reinit(goal_id);
-        st[start_id].g = 0;
-        st[start_id].f = key(st[start_id]);
-        push(start_id);
-        iteration = 1;
-        curr_eps = initial_eps;
-        satisfied_eps = std::numeric_limits<double>::infinity();
-        // goal id "changed" on a fresh search: recompute h of existing states and reorder (:155-162)
-        for (size_t i = 0; i < st.size(); ++i) {
-            if (st[i].made) { int32_t h = 0; smplx_get_goal_heuristic(sp, (int)i, &h); st[i].h = (unsigned int)h; }
+        if (phase == 0) {
+            heap.assign(1, 0);
+            incons.clear();
+            ++call_number;
+            reinit(start_id);
+            reinit(goal_id);
+            st[start_id].g = 0;
+            st[start_id].f = key(st[start_id]);
+            push(start_id);
+            iteration = 1;
+            curr_eps = initial_eps;
+            satisfied_eps = std::numeric_limits<double>::infinity();
+            // goal id "changed" on a fresh search: recompute h of existing states and reorder (:155-162)
+            for (size_t i = 0; i < st.size(); ++i) {
+                if (st[i].made) { int32_t h = 0; smplx_get_goal_heuristic(sp, (int)i, &h); st[i].h = (unsigned int)h; }
+            }
+            reorder_open();
+            num = 0; err = 0;
+            phase = 1;
         }
-        reorder_open();
-        int num = 0, err = 0;
-        while (satisfied_eps > final_eps) {
-            if (curr_eps == satisfied_eps) {
-                if (!improve) break;
-                ++iteration;
-                curr_eps -= delta_eps;
-                curr_eps = std::max(curr_eps, final_eps);
-                for (int s : incons) { st[s].incons = false; push(s); }
-                reorder_open();
-                incons.clear();
+        while (true) {
+            if (phase == 1) {
+                if (!(satisfied_eps > final_eps)) break;
+                if (curr_eps == satisfied_eps) {
+                    if (!improve) break;
+                    ++iteration;
+                    curr_eps -= delta_eps;
+                    curr_eps = std::max(curr_eps, final_eps);
+                    for (int s : incons) { st[s].incons = false; push(s); }
+                    reorder_open();
+                    incons.clear();
+                }
+                phase = 2;
+                num_before = num;
             }
             err = improve_path(num);
+            if (err == R_YIELD) return R_YIELD;
             if (curr_eps == initial_eps) expand_count_init += num;
+            phase = 1;
             if (err) break;
             satisfied_eps = curr_eps;
         }
         expand_count += num;
-        if (satisfied_eps == std::numeric_limits<double>::infinity()) return 0;
+        phase = 3;
+        if (satisfied_eps == std::numeric_limits<double>::infinity()) { solved = 0; return R_DONE; }
         for (int s = goal_id; s >= 0; s = st[s].bp) solution.push_back(s);
         std::reverse(solution.begin(), solution.end());
         cost = (int)st[goal_id].g;
-        return 1;
+        solved = 1;
+        return R_DONE;
     }
+    int num_before = 0;
 };
 
-}  // namespace
-
-int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats)
+void fill_search(Search& S, smplx_space* s, const smplx_search_params* p)
 {
-    if (!s || !p || !stats) return set_error(SMPLX_E_ARG, "null argument");
-    if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
-    if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
-    Search S;
     S.sp = s;
     S.initial_eps = p->initial_eps;
     S.final_eps = std::max(p->final_eps, 1.0);   // ARAStar::setTargetEpsilon (arastar.h:112-114)
@@ -1260,40 +1306,104 @@ int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, 
     S.max_rep = p->max_expansions;
     S.start_id = s->start_id;
     S.goal_id = 0;
-    s->expansion_log.clear();
-    const int capB = s->params.batch_states > 0 ? s->params.batch_states : 4096;
-    const size_t cw = counter_words(capB, s->M);
-    if (int e = s->b_counters.reserve(cw)) return e;
-    HIP_TRY(hipMemsetAsync(s->b_counters.p, 0, sizeof(unsigned long long) * cw, s->stream));
-    const int64_t b0 = s->gpu_batches, h0 = s->cache_hits, m0 = s->cache_misses, c0 = s->committed_evals;
-    std::vector<int> sol;
-    int cost = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    const int ok = S.replan(sol, cost);
-    const auto t1 = std::chrono::steady_clock::now();
-    if (S.error) return S.error;
-    unsigned long long counters[4] = {0, 0, 0, 0};
-    {
-        std::vector<unsigned long long> part(cw);
-        HIP_TRY(hipMemcpy(part.data(), s->b_counters.p, sizeof(unsigned long long) * cw, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cw; ++i) if (i % SMPLX_TALLIES < 4) counters[i % SMPLX_TALLIES] += part[i];
-    }
-    std::memset(stats, 0, sizeof(*stats));
-    stats->solved = ok;
-    stats->path_len = (int)sol.size();
-    stats->cost = cost;
-    stats->expansions = S.expand_count;
-    stats->expansions_init = S.expand_count_init;
-    stats->satisfied_eps = S.satisfied_eps;
-    stats->seconds = std::chrono::duration<double>(t1 - t0).count();
-    stats->gpu_succ_evals = (int64_t)counters[0];
-    stats->grid_lookups = (int64_t)counters[2];
-    stats->committed_succ_evals = s->committed_evals - c0;
-    stats->gpu_batches = s->gpu_batches - b0;
-    stats->cache_hits = s->cache_hits - h0;
-    stats->cache_misses = s->cache_misses - m0;
-    for (int i = 0; i < (int)sol.size() && i < cap; ++i) if (path_ids) path_ids[i] = sol[i];
+}
+
+}  // namespace
+
+static int read_counters(smplx_space* s, size_t cw, unsigned long long counters[4])
+{
+    std::vector<unsigned long long> part(cw);
+    HIP_TRY(hipMemcpy(part.data(), s->b_counters.p, sizeof(unsigned long long) * cw, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) counters[k] = 0;
+    for (size_t i = 0; i < cw; ++i) if (i % SMPLX_TALLIES < 4) counters[i % SMPLX_TALLIES] += part[i];
     return SMPLX_OK;
+}
+
+int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p, int32_t* path_ids, int cap,
+                     smplx_search_stats* stats, double* wall_seconds)
+{
+    if (!spaces || nq <= 0 || !p || !stats) return set_error(SMPLX_E_ARG, "bad argument");
+    std::vector<Search> S(nq);
+    std::vector<size_t> cw(nq);
+    struct Base { int64_t b, h, m, c; };
+    std::vector<Base> base(nq);
+    for (int q = 0; q < nq; ++q) {
+        smplx_space* s = spaces[q];
+        if (!s) return set_error(SMPLX_E_ARG, "null space");
+        if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+        if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
+        fill_search(S[q], s, p);
+        s->expansion_log.clear();
+        const int capB = s->params.batch_states > 0 ? s->params.batch_states : 4096;
+        cw[q] = counter_words(capB, s->M);
+        if (int e = s->b_counters.reserve(cw[q])) return e;
+        HIP_TRY(hipMemsetAsync(s->b_counters.p, 0, sizeof(unsigned long long) * cw[q], s->stream));
+        base[q] = {s->gpu_batches, s->cache_hits, s->cache_misses, s->committed_evals};
+    }
+    // One host thread drives every query: a query runs until it misses, its frontier batch goes to its own
+    // stream, and the thread moves on to the next query; a landed batch is collected when its turn comes again.
+    // Queries never exchange data.
+    std::vector<char> done(nq, 0), waiting(nq, 0);
+    std::vector<double> t_done(nq, 0.0);
+    int remaining = nq;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (remaining > 0) {
+        bool progressed = false;
+        for (int q = 0; q < nq; ++q) {
+            if (done[q]) continue;
+            smplx_space* s = spaces[q];
+            if (waiting[q]) {
+                const hipError_t st = hipEventQuery(s->batch_done);
+                if (st == hipErrorNotReady) continue;
+                if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+                if (int e = collect_batch(s)) return e;
+                waiting[q] = 0;
+            }
+            const int r = S[q].resume();
+            progressed = true;
+            if (S[q].error) return S[q].error;
+            if (r == Search::R_YIELD) { waiting[q] = 1; continue; }
+            done[q] = 1;
+            --remaining;
+            t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        if (!progressed) {
+            // every live query is waiting on the GPU: block on one of them instead of spinning
+            for (int q = 0; q < nq; ++q)
+                if (!done[q] && waiting[q]) { HIP_TRY(hipEventSynchronize(spaces[q]->batch_done)); break; }
+        }
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (wall_seconds) *wall_seconds = wall;
+    for (int q = 0; q < nq; ++q) {
+        smplx_space* s = spaces[q];
+        unsigned long long counters[4];
+        if (int e = read_counters(s, cw[q], counters)) return e;
+        smplx_search_stats& st = stats[q];
+        std::memset(&st, 0, sizeof(st));
+        st.solved = S[q].solved;
+        st.path_len = (int)S[q].solution.size();
+        st.cost = S[q].cost;
+        st.expansions = S[q].expand_count;
+        st.expansions_init = S[q].expand_count_init;
+        st.satisfied_eps = S[q].satisfied_eps;
+        st.seconds = t_done[q];
+        st.gpu_succ_evals = (int64_t)counters[0];
+        st.grid_lookups = (int64_t)counters[2];
+        st.committed_succ_evals = s->committed_evals - base[q].c;
+        st.gpu_batches = s->gpu_batches - base[q].b;
+        st.cache_misses = s->cache_misses - base[q].m;
+        st.cache_hits = (s->cache_hits - base[q].h) - st.cache_misses;   // expansions served without waiting for the GPU
+        if (path_ids)
+            for (int i = 0; i < (int)S[q].solution.size() && i < cap; ++i) path_ids[(size_t)q * cap + i] = S[q].solution[i];
+    }
+    return SMPLX_OK;
+}
+
+int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats)
+{
+    if (!s) return set_error(SMPLX_E_ARG, "null argument");
+    return smplx_plan_multi(&s, 1, p, path_ids, cap, stats, nullptr);
 }
 
 int smplx_expansion_log_size(const smplx_space* s) { return s ? (int)s->expansion_log.size() : 0; }

@@ -11,9 +11,9 @@
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
 // dynamic LDS bytes: the packed model, plus (collision kernels) per-thread scratch
-static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots)
+static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots, int nvars)
 {
-    return blob_bytes + (size_t)(3 * nroot + 12 * nslots) * 8 * SMPLX_BLOCK + (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
+    return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * SMPLX_BLOCK + (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
 }
 
 extern "C" {

@@ -44,6 +44,7 @@ struct ThreadLds {
     unsigned char* stk;       // per-thread byte stack, SoA
     int root_base;            // first double of root positions (3 per tree)
     int slot_base;            // first double of saved transforms (12 per slot)
+    int q_base;               // first double of the configuration's joint values (one per planning variable)
 };
 
 __device__ __forceinline__ double& lds_d(const ThreadLds& L, int e) { return L.d[e * BLOCK + threadIdx.x]; }
@@ -193,12 +194,31 @@ struct EdgeRef {
     double alpha;
 };
 
-__device__ __forceinline__ double config_var(const ModelLds* __restrict__ M, const EdgeRef& e, int v)
+// joint values of the configuration on the edge at parameter alpha
+// (robot_motion_collision_model.h:221-247 diffs, 297-320 interpolate), staged into per-thread LDS with every
+// global load issued before the first use: the FK loop then never waits on HBM for a joint value
+__device__ __forceinline__ void stage_config(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e)
 {
-    const double sv = e.start[v];
-    if (e.alpha == 0.0) return sv;      // start + 0*diff == start exactly
-    const double d = edge_diff(M, v, sv, e.finish[v]);
-    return sv + e.alpha * d;
+    const int nv = M->nvars;
+    double sv[SMPLX_MAX_VARS], fv[SMPLX_MAX_VARS];
+#pragma unroll
+    for (int v = 0; v < SMPLX_MAX_VARS; ++v) {
+        if (v < nv) { sv[v] = e.start[v]; fv[v] = e.finish[v]; }
+    }
+#pragma unroll
+    for (int v = 0; v < SMPLX_MAX_VARS; ++v) {
+        if (v < nv) {
+            double q = sv[v];
+            if (e.alpha != 0.0) q = sv[v] + e.alpha * edge_diff(M, v, sv[v], fv[v]);   // start + 0*diff == start exactly
+            lds_d(L, L.q_base + v) = q;
+        }
+    }
+}
+
+__device__ __forceinline__ double config_var(const ModelLds* __restrict__ M, const ThreadLds& L, int v)
+{
+    (void)M;
+    return lds_d(L, L.q_base + v);
 }
 
 // link transforms of two trees' links for one configuration (slow path of the sphere-sphere pass)
@@ -211,7 +231,7 @@ __device__ __noinline__ void fk_two_links(const ModelLds* __restrict__ M, const 
     const int last = ja > jb ? ja : jb;
     for (int j = 0; j <= last; ++j) {
         const SmplxJoint* jt = &M->joints[j];
-        const double q = jt->var >= 0 ? config_var(M, e, jt->var) : 0.0;
+        const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
         double J[12];
         joint_matrix(jt, q, J);
         if (jt->src == SMPLX_SRC_ROOT) {
@@ -293,10 +313,11 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
     bool pair_hit = false, recheck_all = false;
     unsigned long long pending = 0;   // queued (earlier tree, later tree) pairs, 16 bits each
     int npending = 0;
+    stage_config(M, L, e);
     const int nj = M->njoints;
     for (int j = 0; j < nj; ++j) {
         const SmplxJoint* jt = &M->joints[j];
-        const double q = jt->var >= 0 ? config_var(M, e, jt->var) : 0.0;
+        const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
         double J[12];
         joint_matrix(jt, q, J);
         if (jt->src == SMPLX_SRC_ROOT) {
@@ -554,7 +575,8 @@ __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__
     L.d = reinterpret_cast<double*>(smem + hdr[SMPLX_BH_BYTES]);
     L.root_base = 0;
     L.slot_base = 3 * Mv->nroot;
-    const int nd = 3 * Mv->nroot + 12 * Mv->nslots;
+    L.q_base = 3 * Mv->nroot + 12 * Mv->nslots;
+    const int nd = 3 * Mv->nroot + 12 * Mv->nslots + Mv->nvars;
     L.stk = reinterpret_cast<unsigned char*>(L.d + (size_t)nd * BLOCK);
     __syncthreads();
     return L;

@@ -243,3 +243,31 @@ def test_dual_arm_expand_batch(dual_ctx):
     got = _compare_expand(o, s, Q)
     assert got["flags"].shape[1] == 59          # 3 adaptive slots + 28 rows x 2
     assert (got["flags"] & 1).sum() > 50
+
+
+def test_interleaved_multi_query_equals_each_query_alone(small_cfg):
+    """smplx_plan_multi: independent queries interleaved on one GPU by one host thread (BASELINE config 4 shape).
+    Every query must come out exactly as it does alone -- and as the oracle computes it."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = small_cfg
+    cells = [[-49, 7, 21, -14, -8, -12, 16], [-21, 7, 14, -7, 8, -4, 12], [-35, 14, 7, -14, 4, -8, 8], [-42, 10, 14, -10, 0, -8, 12]]
+    goals = [[cfg.start[i] + c * DEG for i, c in enumerate(cs)] for cs in cells]
+    spaces = []
+    for g in goals:
+        sp = capi.Space.from_config(cfg, batch_states=512)
+        sp.set_goal_joint(g, cfg.goal_tol)
+        sp.set_start(cfg.start)
+        spaces.append(sp)
+    multi, wall = capi.Space.plan_multi(spaces, 5.0, 1.0, 1.0, True, True, 4000, 2500)
+    assert wall > 0 and len(multi) == 4
+    for g, m in zip(goals, multi):
+        o = Oracle(cfg)
+        o.set_goal_joint(g, cfg.goal_tol)
+        o.set_start(cfg.start)
+        o.search_params(5.0, 1.0, 1.0, True, True, 4000, 2500)
+        e = o.plan()
+        assert e["ok"] == m["solved"] and e["cost"] == m["cost"] and e["expansions"] == m["expansions"]
+        assert np.array_equal(e["expansion_log"], m["expansion_log"])
+        assert np.array_equal(e["path"], m["path"])
+    assert sum(m["gpu_batches"] for m in multi) > 4
