@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--planner-expansions", type=int, default=40000)
     ap.add_argument("--multi-queries", type=int, default=16, help="queries interleaved on one GPU in the planner leg")
+    ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the planner_multi leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     args = ap.parse_args()
@@ -229,17 +230,20 @@ def main():
         # CPU leg ran, and in tests/test_gpu_parity.py for all of them.
         nq, nb = args.multi_queries, args.planner_expansions
         spaces = []
+        grid_h = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
+        model_h = capi.Model(cfg.robot_text)
         for qi in range(nq):
             g = [a + c * scenes.DEG for a, c in zip(cfg.goal, rank_goal_shift(qi))]
-            sp = capi.Space.from_config(cfg, batch_states=args.batch)
+            sp = capi.Space(model_h, grid_h, cfg.mprim, cfg.params, args.batch)   # one scene, one robot, Q queries
             okq, _ = sp.state_valid_batch(np.array([g]))
             sp.set_goal_joint(g if okq[0] else cfg.goal, cfg.goal_tol)
             sp.set_start(cfg.start)
             spaces.append(sp)
-        res, wall = capi.Space.plan_multi(spaces, p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+        res, wall = capi.Space.plan_multi(spaces, p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb,
+                                          host_threads=args.host_threads)
         tot = sum(r["expansions"] for r in res)
         out["planner_multi"] = {
-            "queries": nq, "expansion_bound_per_query": nb, "wall_seconds": round(wall, 4),
+            "queries": nq, "host_threads": args.host_threads, "expansion_bound_per_query": nb, "wall_seconds": round(wall, 4),
             "states_expanded_per_s": round(tot / wall, 1), "expansions_total": tot,
             "solved": int(sum(r["solved"] for r in res)),
             "gpu_succ_evals_total": int(sum(r["gpu_succ_evals"] for r in res)),

@@ -186,9 +186,11 @@ int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, 
  * GPU: a query runs until it misses, its frontier batch is issued on its own stream, and the thread moves on to
  * the next query.  No data is exchanged between queries; every query's result equals what smplx_plan gives alone.
  * path_ids holds nq rows of cap ids (may be NULL); stats holds nq entries (seconds = completion time since the
- * start of the call); wall_seconds = duration of the whole call.  (BASELINE config 4: 128 queries per GPU.) */
+ * start of the call); wall_seconds = duration of the whole call.  Queries created on the same smplx_grid and
+ * smplx_model with the same primitives share launches (one cross-query frontier batch per sweep); host_threads > 1
+ * splits them into that many slices, each driven by its own host thread.  (BASELINE config 4: 128 queries per GPU.) */
 int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p, int32_t* path_ids, int cap,
-                     smplx_search_stats* stats, double* wall_seconds);
+                     smplx_search_stats* stats, double* wall_seconds, int host_threads);
 int smplx_expansion_log_size(const smplx_space* s);
 int smplx_expansion_log(const smplx_space* s, int32_t* out);
 /* ManipLattice::extractPath for a plain id path (manip_lattice.cpp:2018-2155): q[len][nvars] */

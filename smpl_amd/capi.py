@@ -340,7 +340,8 @@ class Space:
         return out
 
     @staticmethod
-    def plan_multi(spaces, eps0, eps_final, eps_delta, improve=True, bounded=False, max_init=0, max_rep=0, cap=4096):
+    def plan_multi(spaces, eps0, eps_final, eps_delta, improve=True, bounded=False, max_init=0, max_rep=0, cap=4096,
+                   host_threads=1):
         """Interleaved ARA* over independent queries on one GPU (smplx_plan_multi)."""
         nq = len(spaces)
         P = SearchParams(eps0, eps_final, eps_delta, int(improve), int(bounded), max_init, max_rep)
@@ -348,7 +349,7 @@ class Space:
         H = (C.c_void_p * nq)(*[sp.h for sp in spaces])
         ids = np.zeros((nq, cap), np.int32)
         wall = C.c_double()
-        _chk(lib().smplx_plan_multi(H, nq, C.byref(P), _p(ids, _ip), cap, St, C.byref(wall)))
+        _chk(lib().smplx_plan_multi(H, nq, C.byref(P), _p(ids, _ip), cap, St, C.byref(wall), int(host_threads)))
         out = []
         for q, sp in enumerate(spaces):
             d = {f: getattr(St[q], f) for f, _ in SearchStats._fields_}

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/smpl_amd.h"
@@ -190,7 +191,11 @@ struct smplx_space {
     std::vector<int32_t> inflight;
     hipEvent_t batch_done = nullptr;
     // stats
-    int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0;
+    int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0, gpu_evals = 0;
+    // cross-query batches (smplx_plan_multi): query table + per-state query index, owned by the leading space
+    DevBuf<const SmplxSpaceDev*> b_stab;
+    DevBuf<unsigned short> b_stateq;
+    PinBuf<unsigned short> p_stateq;
     std::vector<int32_t> eval_count;    // per id: evaluated (active) primitives, for committed_evals
     std::vector<int32_t> expansion_log;
     // optional per-kernel timing of expand launches (bench.py roofline): 3 events per launch
@@ -335,7 +340,7 @@ ExpandWork carve_work(void* base, int B, int M)
 
 int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
-                  hipStream_t stream)
+                  hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr)
 {
     const ExpandWork k = carve_work(d_work, B, s->M);
     hipEvent_t* ev = nullptr;
@@ -347,19 +352,19 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (ev) (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
-                           k.goal_dist, k.state_bad, k.state_lookups);
+                           k.goal_dist, k.state_bad, k.state_lookups, stab, state_q);
         if (ev) (void)hipEventRecord(ev[1], stream);
         hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
-                           d_counters, (const int*)nullptr);
+                           d_counters, (const int*)nullptr, stab, state_q);
         if (ev) (void)hipEventRecord(ev[2], stream);
     } else {
         const size_t lm = s->blob_bytes;
         hipLaunchKernelGGL(k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
-                           k.goal_dist, k.work_count);
+                           k.goal_dist, k.work_count, stab, state_q);
         hipLaunchKernelGGL(k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
-                           k.work, k.work_count, k.capacity);
+                           k.work, k.work_count, k.capacity, stab, state_q);
         if (ev) (void)hipEventRecord(ev[0], stream);
         const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK);
         hipLaunchKernelGGL(k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
@@ -368,13 +373,13 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         if (ev) (void)hipEventRecord(ev[1], stream);
         hipLaunchKernelGGL(k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, d_flags, d_coord, d_sq, d_h,
-                           d_cost, d_lookups, d_counters);
+                           d_cost, d_lookups, d_counters, stab, state_q);
         if (ev) (void)hipEventRecord(ev[2], stream);
         // edges whose waypoints did not fit the work list (work_count[1] of them; normally none): every block of
         // this pass returns at once when the count is zero
         hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
-                           d_counters, (const int*)(k.work_count + 8 * 32));
+                           d_counters, (const int*)(k.work_count + 8 * 32), stab, state_q);
     }
     HIP_TRY(hipGetLastError());
     return SMPLX_OK;
@@ -430,12 +435,9 @@ void reset_lattice(smplx_space* s)
 }
 
 // evaluate the successors of `id` plus hinted frontier states in one frontier batch
-// enqueue one frontier batch (state `id` plus hinted frontier states) on the space's stream: upload, the
-// expansion pipeline, download, completion event.  Returns without waiting.
-int issue_batch(smplx_space* s, int id)
+// the states of the next frontier batch: `id` plus the hinted frontier states that are neither cached nor in flight
+void select_batch(smplx_space* s, int id, int cap)
 {
-    const int N = s->N, M = s->M;
-    const int cap = s->params.batch_states > 0 ? s->params.batch_states : 4096;
     std::vector<int32_t>& batch = s->inflight;
     batch.clear();
     batch.push_back(id);
@@ -448,6 +450,16 @@ int issue_batch(smplx_space* s, int id)
         batch.push_back(hId);
     }
     s->hint.clear();
+}
+
+// enqueue one frontier batch (state `id` plus hinted frontier states) on the space's stream: upload, the
+// expansion pipeline, download, completion event.  Returns without waiting.
+int issue_batch(smplx_space* s, int id)
+{
+    const int N = s->N, M = s->M;
+    const int cap = s->params.batch_states > 0 ? s->params.batch_states : 4096;
+    select_batch(s, id, cap);
+    std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
     const size_t BM = (size_t)B * M;
     if (int e = reserve_expand(s, B)) return e;
@@ -471,8 +483,9 @@ int issue_batch(smplx_space* s, int id)
 }
 
 // the batch in flight has completed: turn its dense outputs into cached successor records
-int collect_batch(smplx_space* s)
+int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0)
 {
+    if (!src) src = s;   // a cross-query batch lands in the leading space's buffers, at row `first`
     const int N = s->N, M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
@@ -481,21 +494,22 @@ int collect_batch(smplx_space* s)
         s->cache_off[sid] = (int64_t)s->recs.size();
         int cnt = 0, evals = 0;
         for (int p = 0; p < M; ++p) {
-            const size_t k = (size_t)i * M + p;
-            const unsigned char f = s->p_flags.p[k];
+            const size_t k = (first + (size_t)i) * M + p;
+            const unsigned char f = src->p_flags.p[k];
             if (!(f & SMPLX_F_INACTIVE)) ++evals;
             if (!(f & SMPLX_F_VALID)) continue;
             smplx_space::Rec r;
             r.cost = s->actions.dev.cost[p];
-            r.h = s->p_h.p[k];
+            r.h = src->p_h.p[k];
             r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
             s->recs.push_back(r);
-            s->rec_coord.insert(s->rec_coord.end(), &s->p_coord.p[k * N], &s->p_coord.p[k * N] + N);
-            s->rec_q.insert(s->rec_q.end(), &s->p_sq.p[k * N], &s->p_sq.p[k * N] + N);
+            s->rec_coord.insert(s->rec_coord.end(), &src->p_coord.p[k * N], &src->p_coord.p[k * N] + N);
+            s->rec_q.insert(s->rec_q.end(), &src->p_sq.p[k * N], &src->p_sq.p[k * N] + N);
             ++cnt;
         }
         s->cache_cnt[sid] = cnt;
         s->eval_count[sid] = evals;
+        s->gpu_evals += evals;
     }
     s->inflight.clear();
     return SMPLX_OK;
@@ -1219,8 +1233,11 @@ struct Search {
                 sp->hint.clear();
                 for (size_t i = 2; i < heap.size() && (int)sp->hint.size() < cap - 1; ++i) sp->hint.push_back(heap[i]);
                 ++sp->cache_misses;
-                error = issue_batch(sp, m);
-                if (error) return 99;
+                miss_id = m;
+                if (!defer_issue) {
+                    error = issue_batch(sp, m);
+                    if (error) return 99;
+                }
                 return R_YIELD;
             }
             pop();
@@ -1292,6 +1309,8 @@ struct Search {
         return R_DONE;
     }
     int num_before = 0;
+    int miss_id = -1;
+    bool defer_issue = false;   // cross-query batching: the caller gathers the misses of many queries into one launch
 };
 
 void fill_search(Search& S, smplx_space* s, const smplx_search_params* p)
@@ -1310,6 +1329,81 @@ void fill_search(Search& S, smplx_space* s, const smplx_search_params* p)
 
 }  // namespace
 
+// One slice [q0, q1) of a set of queries that share scene, robot and primitives, driven by the calling thread:
+// every sweep runs each live query until it misses, gathers the misses into ONE cross-query frontier batch
+// (per-state query index -> that query's goal and BFS grid), and hands the results back.
+int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, double* t_done,
+              std::chrono::steady_clock::time_point t0)
+{
+    smplx_space* lead = spaces[q0];
+    const int nq = q1 - q0;
+    int remaining = nq;
+        const int N = lead->N, M = lead->M;
+        {
+            std::vector<const SmplxSpaceDev*> tab(nq);
+            for (int q = 0; q < nq; ++q) tab[q] = spaces[q0 + q]->d_space;
+            if (int e = lead->b_stab.reserve(nq)) return e;
+            HIP_TRY(hipMemcpy(lead->b_stab.p, tab.data(), sizeof(void*) * nq, hipMemcpyHostToDevice));
+        }
+        for (int q = q0; q < q1; ++q) S[q].defer_issue = true;
+        // hinted frontier states per query and sweep: enough to keep a query fed, small enough that the dense
+        // download of a sweep stays in the hundreds of kilobytes
+        const int cap_q = std::max(16, std::min(512, (lead->params.batch_states > 0 ? lead->params.batch_states : 4096) / std::max(1, nq / 4)));
+        std::vector<int> reqs;
+        while (remaining > 0) {
+            reqs.clear();
+            for (int q = q0; q < q1; ++q) {
+                if (done[q]) continue;
+                const int r = S[q].resume();
+                if (S[q].error) return S[q].error;
+                if (r == Search::R_YIELD) { reqs.push_back(q); continue; }
+                done[q] = 1;
+                --remaining;
+                t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (reqs.empty()) break;
+            size_t total = 0;
+            for (int q : reqs) { select_batch(spaces[q], S[q].miss_id, cap_q); total += spaces[q]->inflight.size(); }
+            const int B = (int)total;
+            const size_t BM = total * M;
+            int e;
+            if ((e = reserve_expand(lead, B))) return e;
+            if ((e = lead->b_stateq.reserve(total))) return e;
+            if ((e = lead->p_stateq.reserve(total))) return e;
+            if ((e = lead->p_q.reserve(total * N))) return e;
+            if ((e = lead->p_flags.reserve(BM))) return e;
+            if ((e = lead->p_coord.reserve(BM * N))) return e;
+            if ((e = lead->p_sq.reserve(BM * N))) return e;
+            if ((e = lead->p_h.reserve(BM))) return e;
+            size_t row = 0;
+            for (int q : reqs) {
+                const smplx_space* sq = spaces[q];
+                for (int32_t id : sq->inflight) {
+                    std::memcpy(&lead->p_q.p[row * N], &sq->qs[(size_t)id * N], sizeof(double) * N);
+                    lead->p_stateq.p[row] = (unsigned short)(q - q0);
+                    ++row;
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(lead->b_q.p, lead->p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, lead->stream));
+            HIP_TRY(hipMemcpyAsync(lead->b_stateq.p, lead->p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, lead->stream));
+            if ((e = launch_expand(lead, lead->b_q.p, B, lead->b_flags.p, lead->b_coord.p, lead->b_sq.p, lead->b_h.p, lead->b_cost.p,
+                                   lead->b_lookups.p, lead->b_work.p, nullptr, lead->stream, lead->b_stab.p, lead->b_stateq.p))) return e;
+            HIP_TRY(hipMemcpyAsync(lead->p_flags.p, lead->b_flags.p, BM, hipMemcpyDeviceToHost, lead->stream));
+            HIP_TRY(hipMemcpyAsync(lead->p_h.p, lead->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, lead->stream));
+            HIP_TRY(hipMemcpyAsync(lead->p_coord.p, lead->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost, lead->stream));
+            HIP_TRY(hipMemcpyAsync(lead->p_sq.p, lead->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost, lead->stream));
+            HIP_TRY(hipStreamSynchronize(lead->stream));
+            ++lead->gpu_batches;
+            row = 0;
+            for (int q : reqs) {
+                const size_t nb = spaces[q]->inflight.size();
+                if ((e = collect_batch(spaces[q], lead, row))) return e;
+                row += nb;
+            }
+        }
+    return SMPLX_OK;
+}
+
 static int read_counters(smplx_space* s, size_t cw, unsigned long long counters[4])
 {
     std::vector<unsigned long long> part(cw);
@@ -1320,12 +1414,12 @@ static int read_counters(smplx_space* s, size_t cw, unsigned long long counters[
 }
 
 int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p, int32_t* path_ids, int cap,
-                     smplx_search_stats* stats, double* wall_seconds)
+                     smplx_search_stats* stats, double* wall_seconds, int host_threads)
 {
     if (!spaces || nq <= 0 || !p || !stats) return set_error(SMPLX_E_ARG, "bad argument");
     std::vector<Search> S(nq);
     std::vector<size_t> cw(nq);
-    struct Base { int64_t b, h, m, c; };
+    struct Base { int64_t b, h, m, c, g; };
     std::vector<Base> base(nq);
     for (int q = 0; q < nq; ++q) {
         smplx_space* s = spaces[q];
@@ -1338,47 +1432,80 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         cw[q] = counter_words(capB, s->M);
         if (int e = s->b_counters.reserve(cw[q])) return e;
         HIP_TRY(hipMemsetAsync(s->b_counters.p, 0, sizeof(unsigned long long) * cw[q], s->stream));
-        base[q] = {s->gpu_batches, s->cache_hits, s->cache_misses, s->committed_evals};
+        base[q] = {s->gpu_batches, s->cache_hits, s->cache_misses, s->committed_evals, s->gpu_evals};
     }
-    // One host thread drives every query: a query runs until it misses, its frontier batch goes to its own
-    // stream, and the thread moves on to the next query; a landed batch is collected when its turn comes again.
-    // Queries never exchange data.
     std::vector<char> done(nq, 0), waiting(nq, 0);
     std::vector<double> t_done(nq, 0.0);
     int remaining = nq;
+    // Queries that share the scene (same grid handle), robot and primitives can share launches: their misses are
+    // gathered into ONE cross-query frontier batch per sweep (per-state query index -> that query's goal and BFS
+    // grid).  Otherwise each query issues its own batches on its own stream.
+    bool grouped = nq > 1;
+    for (int q = 1; q < nq && grouped; ++q) {
+        const smplx_space* a = spaces[0];
+        const smplx_space* b = spaces[q];
+        grouped = a->grid == b->grid && a->blob_bytes == b->blob_bytes &&
+                  std::memcmp(a->hs.model_blob, b->hs.model_blob, a->blob_bytes) == 0 &&
+                  std::memcmp(&a->hs.actions, &b->hs.actions, sizeof(SmplxActionsDev)) == 0 && a->fused_mode == b->fused_mode;
+    }
     const auto t0 = std::chrono::steady_clock::now();
-    while (remaining > 0) {
-        bool progressed = false;
-        for (int q = 0; q < nq; ++q) {
-            if (done[q]) continue;
-            smplx_space* s = spaces[q];
-            if (waiting[q]) {
-                const hipError_t st = hipEventQuery(s->batch_done);
-                if (st == hipErrorNotReady) continue;
-                if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
-                if (int e = collect_batch(s)) return e;
-                waiting[q] = 0;
-            }
-            const int r = S[q].resume();
-            progressed = true;
-            if (S[q].error) return S[q].error;
-            if (r == Search::R_YIELD) { waiting[q] = 1; continue; }
-            done[q] = 1;
-            --remaining;
-            t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (grouped) {
+        // host threads: each drives a contiguous slice of the queries with its own leading space / stream, so the
+        // commit work (hashing, heap, record ingestion) of different slices overlaps; the GPU serves all of them
+        int nthreads = host_threads > 0 ? host_threads : 1;
+        nthreads = std::max(1, std::min(nthreads, nq));
+        std::vector<int> rc(nthreads, SMPLX_OK);
+        std::vector<std::string> msg(nthreads);
+        auto worker = [&](int t) {
+            const int q0 = (int)((long long)nq * t / nthreads), q1 = (int)((long long)nq * (t + 1) / nthreads);
+            rc[t] = run_group(spaces, S.data(), q0, q1, done.data(), t_done.data(), t0);
+            if (rc[t] != SMPLX_OK) msg[t] = g_error;
+        };
+        if (nthreads == 1) {
+            worker(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthreads; ++t) th.emplace_back(worker, t);
+            for (auto& x : th) x.join();
         }
-        if (!progressed) {
-            // every live query is waiting on the GPU: block on one of them instead of spinning
-            for (int q = 0; q < nq; ++q)
-                if (!done[q] && waiting[q]) { HIP_TRY(hipEventSynchronize(spaces[q]->batch_done)); break; }
+        for (int t = 0; t < nthreads; ++t) if (rc[t] != SMPLX_OK) return set_error(rc[t], msg[t]);
+        remaining = 0;
+    } else {
+        // One host thread drives every query: a query runs until it misses, its frontier batch goes to its own
+        // stream, and the thread moves on to the next query; a landed batch is collected when its turn comes again.
+        while (remaining > 0) {
+            bool progressed = false;
+            for (int q = 0; q < nq; ++q) {
+                if (done[q]) continue;
+                smplx_space* s = spaces[q];
+                if (waiting[q]) {
+                    const hipError_t st = hipEventQuery(s->batch_done);
+                    if (st == hipErrorNotReady) continue;
+                    if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+                    if (int e = collect_batch(s)) return e;
+                    waiting[q] = 0;
+                }
+                const int r = S[q].resume();
+                progressed = true;
+                if (S[q].error) return S[q].error;
+                if (r == Search::R_YIELD) { waiting[q] = 1; continue; }
+                done[q] = 1;
+                --remaining;
+                t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (!progressed) {
+                // every live query is waiting on the GPU: block on one of them instead of spinning
+                for (int q = 0; q < nq; ++q)
+                    if (!done[q] && waiting[q]) { HIP_TRY(hipEventSynchronize(spaces[q]->batch_done)); break; }
+            }
         }
     }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (wall_seconds) *wall_seconds = wall;
     for (int q = 0; q < nq; ++q) {
         smplx_space* s = spaces[q];
-        unsigned long long counters[4];
-        if (int e = read_counters(s, cw[q], counters)) return e;
+        unsigned long long counters[4] = {0, 0, 0, 0};
+        if (!grouped) { if (int e = read_counters(s, cw[q], counters)) return e; }
         smplx_search_stats& st = stats[q];
         std::memset(&st, 0, sizeof(st));
         st.solved = S[q].solved;
@@ -1388,7 +1515,7 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         st.expansions_init = S[q].expand_count_init;
         st.satisfied_eps = S[q].satisfied_eps;
         st.seconds = t_done[q];
-        st.gpu_succ_evals = (int64_t)counters[0];
+        st.gpu_succ_evals = s->gpu_evals - base[q].g;
         st.grid_lookups = (int64_t)counters[2];
         st.committed_succ_evals = s->committed_evals - base[q].c;
         st.gpu_batches = s->gpu_batches - base[q].b;
@@ -1403,7 +1530,7 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
 int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats)
 {
     if (!s) return set_error(SMPLX_E_ARG, "null argument");
-    return smplx_plan_multi(&s, 1, p, path_ids, cap, stats, nullptr);
+    return smplx_plan_multi(&s, 1, p, path_ids, cap, stats, nullptr, 1);
 }
 
 int smplx_expansion_log_size(const smplx_space* s) { return s ? (int)s->expansion_log.size() : 0; }

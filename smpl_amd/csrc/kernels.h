@@ -18,24 +18,29 @@ static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots, i
 
 extern "C" {
 __global__ void k_state_prep(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist,
-                             unsigned char* parent_valid, int* parent_lookups);
+                             unsigned char* parent_valid, int* parent_lookups,
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_expand(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
                          const unsigned char* parent_valid, const int* parent_lookups, unsigned char* out_flags,
                          int* out_coord, double* out_q, int* out_h, int* out_cost, int* out_lookups,
-                         unsigned long long* counters, const int* deferred_count);
+                         unsigned long long* counters, const int* deferred_count,
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_prep(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist,
-                            int* work_count);
+                            int* work_count,
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_setup(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
                              unsigned char* out_flags, double* out_q, int* edge_w, int* edge_lookups,
                              unsigned char* edge_bad, int* state_lookups, unsigned char* state_bad, unsigned int* work,
-                             int* work_count, int capacity);
+                             int* work_count, int capacity,
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_configs(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* out_q,
                                const int* edge_w, int* edge_lookups, unsigned char* edge_bad, int* state_lookups,
                                unsigned char* state_bad, const unsigned int* work, const int* work_count, int capacity);
 __global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const int* edge_w,
                               const int* edge_lookups, const unsigned char* edge_bad, const int* state_lookups,
                               const unsigned char* state_bad, unsigned char* out_flags, int* out_coord, double* out_q,
-                              int* out_h, int* out_cost, int* out_lookups, unsigned long long* counters);
+                              int* out_h, int* out_cost, int* out_lookups, unsigned long long* counters,
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

@@ -596,16 +596,17 @@ __device__ __forceinline__ ModelLds setup_model_only(const SmplxSpaceDev* __rest
 
 extern "C" __global__ void __launch_bounds__(BLOCK)
 k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
-             double* __restrict__ goal_dist, unsigned char* __restrict__ parent_valid, int* __restrict__ parent_lookups)
+             double* __restrict__ goal_dist, unsigned char* __restrict__ parent_valid, int* __restrict__ parent_lookups,
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     ModelLds Mv;
     ThreadLds L = setup_lds(S, smem, &Mv);
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
-    const SmplxBfsDev bfs = S->bfs;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= B) return;
+    const SmplxBfsDev bfs = (stab ? stab[state_q[i]] : S)->bfs;   // per-query data in a cross-query batch
     const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
     double p[3];
     planning_fk(M, q, p);
@@ -667,7 +668,8 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
          const int* __restrict__ parent_lookups,
          unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
          int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
-         unsigned long long* __restrict__ counters, const int* __restrict__ deferred_count)
+         unsigned long long* __restrict__ counters, const int* __restrict__ deferred_count,
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // second pass after the pipeline (deferred_count != nullptr): nothing to do in the common case
@@ -678,7 +680,6 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
     ThreadLds L = setup_lds(S, smem, &Mv);
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
-    const SmplxBfsDev bfs = S->bfs;
     const int nprims = A.nprims;
     const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
     bool in_range = tid < (long long)B * nprims;
@@ -695,6 +696,8 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
         const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
         double* sq = out_q + tid * nv;
         int* sc = out_coord + tid * nv;
+        const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;   // per-query goal and BFS grid
+        const SmplxBfsDev bfs = Sq->bfs;
         const int type = A.type[pi];
         int h = 0, cost = 0;
         bool have_action = false;
@@ -714,8 +717,8 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
                     sq[v] = d + parent[v];
                 }
                 have_action = true;
-            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && S->goal.type == SMPLX_GOAL_JOINT) {
-                for (int v = 0; v < nv; ++v) sq[v] = S->goal.angles[v];   // :551-559
+            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) {
+                for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];   // :551-559
                 have_action = true;
             }
         }
@@ -740,14 +743,14 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
                     bool is_goal;
                     double p[3];
                     planning_fk(M, sq, p);
-                    if (S->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
+                    if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
                         is_goal = true;
                         for (int v = 0; v < nv; ++v)
-                            if (fabs((double)(sc[v] - S->goal.coord[v])) > S->goal.angle_tol[v]) is_goal = false;
+                            if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = false;
                     } else {                                      // XYZ goal :1672-1687
-                        is_goal = fabs(p[0] - S->goal.xyz[0]) <= S->goal.xyz_tol[0] &&
-                                  fabs(p[1] - S->goal.xyz[1]) <= S->goal.xyz_tol[1] &&
-                                  fabs(p[2] - S->goal.xyz[2]) <= S->goal.xyz_tol[2];
+                        is_goal = fabs(p[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] &&
+                                  fabs(p[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
+                                  fabs(p[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
                     }
                     int c[3];
                     world_to_cell(grid, p, c);
@@ -792,16 +795,17 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
 
 extern "C" __global__ void __launch_bounds__(BLOCK)
 k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
-            double* __restrict__ goal_dist, int* __restrict__ work_count)
+            double* __restrict__ goal_dist, int* __restrict__ work_count,
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const ModelLds Mv = setup_model_only(S, smem);
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
-    const SmplxBfsDev bfs = S->bfs;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i <= SMPLX_WORK_SHARDS) work_count[i * SMPLX_SHARD_STRIDE] = 0;   // shard counters + deferred count
     if (i >= B) return;
+    const SmplxBfsDev bfs = (stab ? stab[state_q[i]] : S)->bfs;
     const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
     double p[3];
     planning_fk(M, q, p);
@@ -815,7 +819,8 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
              const double* __restrict__ goal_dist, unsigned char* __restrict__ out_flags, double* __restrict__ out_q,
              int* __restrict__ edge_w, int* __restrict__ edge_lookups, unsigned char* __restrict__ edge_bad,
              int* __restrict__ state_lookups, unsigned char* __restrict__ state_bad,
-             unsigned int* __restrict__ work, int* __restrict__ work_count, int capacity)
+             unsigned int* __restrict__ work, int* __restrict__ work_count, int capacity,
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const ModelLds Mv = setup_model_only(S, smem);
@@ -833,6 +838,7 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
         const int nv = M->nvars;
         const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
         double* sq = out_q + tid * nv;
+        const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
         const int type = A.type[pi];
         bool have_action = false;
         if (pi == 0) { state_lookups[si] = 0; state_bad[si] = 0; }
@@ -851,8 +857,8 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
                     sq[v] = d + parent[v];
                 }
                 have_action = true;
-            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && S->goal.type == SMPLX_GOAL_JOINT) {
-                for (int v = 0; v < nv; ++v) sq[v] = S->goal.angles[v];
+            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) {
+                for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];
                 have_action = true;
             }
         }
@@ -982,14 +988,14 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               const int* __restrict__ state_lookups, const unsigned char* __restrict__ state_bad,
               unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
               int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
-              unsigned long long* __restrict__ counters)
+              unsigned long long* __restrict__ counters,
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const ModelLds Mv = setup_model_only(S, smem);
     const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
-    const SmplxBfsDev bfs = S->bfs;
     const int nprims = A.nprims;
     const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = tid < (long long)B * nprims;
@@ -1000,6 +1006,8 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         const int pi = (int)(tid - (long long)si * nprims);
         const int nv = M->nvars;
         flags = out_flags[tid];
+        const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
+        const SmplxBfsDev bfs = Sq->bfs;
         if (pi == 0) { slk = state_lookups[si]; ncfg = 1; }
         int h = 0, cost = 0;
         if (!(flags & (SMPLX_F_INACTIVE | SMPLX_F_DEFERRED))) evaluated = 1;   // deferred edges are tallied by the fused pass
@@ -1018,14 +1026,14 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                 double p[3];
                 planning_fk(M, sq, p);
                 bool is_goal;
-                if (S->goal.type == SMPLX_GOAL_JOINT) {
+                if (Sq->goal.type == SMPLX_GOAL_JOINT) {
                     is_goal = true;
                     for (int v = 0; v < nv; ++v)
-                        if (fabs((double)(sc[v] - S->goal.coord[v])) > S->goal.angle_tol[v]) is_goal = false;
+                        if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = false;
                 } else {
-                    is_goal = fabs(p[0] - S->goal.xyz[0]) <= S->goal.xyz_tol[0] &&
-                              fabs(p[1] - S->goal.xyz[1]) <= S->goal.xyz_tol[1] &&
-                              fabs(p[2] - S->goal.xyz[2]) <= S->goal.xyz_tol[2];
+                    is_goal = fabs(p[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] &&
+                              fabs(p[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
+                              fabs(p[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
                 }
                 int c[3];
                 world_to_cell(grid, p, c);

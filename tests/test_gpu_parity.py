@@ -245,7 +245,8 @@ def test_dual_arm_expand_batch(dual_ctx):
     assert (got["flags"] & 1).sum() > 50
 
 
-def test_interleaved_multi_query_equals_each_query_alone(small_cfg):
+@pytest.mark.parametrize("shared_scene", [True, False])
+def test_interleaved_multi_query_equals_each_query_alone(small_cfg, shared_scene):
     """smplx_plan_multi: independent queries interleaved on one GPU by one host thread (BASELINE config 4 shape).
     Every query must come out exactly as it does alone -- and as the oracle computes it."""
     from oracle_binding import Oracle
@@ -254,12 +255,17 @@ def test_interleaved_multi_query_equals_each_query_alone(small_cfg):
     cells = [[-49, 7, 21, -14, -8, -12, 16], [-21, 7, 14, -7, 8, -4, 12], [-35, 14, 7, -14, 4, -8, 8], [-42, 10, 14, -10, 0, -8, 12]]
     goals = [[cfg.start[i] + c * DEG for i, c in enumerate(cs)] for cs in cells]
     spaces = []
+    # shared grid + model handles -> the misses of all queries ride in ONE cross-query launch per sweep;
+    # separate handles -> every query issues its own batches on its own stream
+    grid = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
+    model = capi.Model(cfg.robot_text)
     for g in goals:
-        sp = capi.Space.from_config(cfg, batch_states=512)
+        sp = (capi.Space(model, grid, cfg.mprim, cfg.params, 512) if shared_scene
+              else capi.Space.from_config(cfg, batch_states=512))
         sp.set_goal_joint(g, cfg.goal_tol)
         sp.set_start(cfg.start)
         spaces.append(sp)
-    multi, wall = capi.Space.plan_multi(spaces, 5.0, 1.0, 1.0, True, True, 4000, 2500)
+    multi, wall = capi.Space.plan_multi(spaces, 5.0, 1.0, 1.0, True, True, 4000, 2500, host_threads=2 if shared_scene else 1)
     assert wall > 0 and len(multi) == 4
     for g, m in zip(goals, multi):
         o = Oracle(cfg)
@@ -271,3 +277,5 @@ def test_interleaved_multi_query_equals_each_query_alone(small_cfg):
         assert np.array_equal(e["expansion_log"], m["expansion_log"])
         assert np.array_equal(e["path"], m["path"])
     assert sum(m["gpu_batches"] for m in multi) > 4
+    if shared_scene:
+        assert multi[1]["gpu_batches"] == 0 and multi[3]["gpu_batches"] == 0   # slice leaders (0 and 2) launched for their slices
