@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--planner-expansions", type=int, default=40000)
-    ap.add_argument("--multi-queries", type=int, default=16, help="queries interleaved on one GPU in the planner leg")
+    ap.add_argument("--multi-queries", type=int, default=32, help="queries interleaved on one GPU in the planner leg")
     ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the planner_multi leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
@@ -102,8 +102,9 @@ def main():
     space.set_start(cfg.start)
     # a real frontier: run the search far enough to own >= B states, take the first B created
     p = cfg.params
-    warm = space.plan(p.eps0, p.eps_final, p.eps_delta, True, True, 1500, 1500)
     B = args.batch
+    nwarm = max(1500, B // 3)
+    warm = space.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nwarm, nwarm)
     if space.num_states() <= B:
         raise SystemExit(f"search produced only {space.num_states()} states, need {B}")
     Q = np.stack([space.get_state(i)[0] for i in range(1, B + 1)])

@@ -82,7 +82,9 @@ typedef struct smplx_params {
     int32_t batch_states;             /* frontier batch B (0 = default 4096) */
     int32_t reserved;                 /* bit 0: fused mode -- one GPU thread walks a whole edge in the
                                          reference's waypoint order (exact reference lookup tallies);
-                                         default 0: waypoint-parallel pipeline (same results, faster) */
+                                         default 0: waypoint-parallel pipeline (same results, faster);
+                                         bit 1: test hook -- a tiny work list, so that most edges take the
+                                         deferred (fused) pass of the pipeline */
 } smplx_params;
 
 /* RobotPlanningSpace::init + insertHeuristic (smpl/include/smpl/graph/robot_planning_space.h:68,89;

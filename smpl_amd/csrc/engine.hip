@@ -165,6 +165,7 @@ struct smplx_space {
     DevBuf<unsigned char> b_flags, b_work;
     DevBuf<int32_t> b_coord, b_h, b_cost, b_lookups, b_way;
     bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
+    bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
     DevBuf<unsigned long long> b_counters;
     PinBuf<double> p_q, p_sq;
     PinBuf<unsigned char> p_flags;
@@ -342,7 +343,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
                   hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr)
 {
-    const ExpandWork k = carve_work(d_work, B, s->M);
+    ExpandWork k = carve_work(d_work, B, s->M);
+    if (s->tiny_work_list) k.capacity = 8 * 16;   // test hook: almost every edge overflows into the deferred pass
     hipEvent_t* ev = nullptr;
     if (s->prof_used + 3 <= s->prof_events.size()) { ev = &s->prof_events[s->prof_used]; s->prof_used += 3; }
     const int bs = blocks_for(B, SMPLX_BLOCK);
@@ -684,6 +686,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->grid = grid;
     s->params = *params;
     s->fused_mode = (params->reserved & 1) != 0;
+    s->tiny_work_list = (params->reserved & 2) != 0;
     s->N = s->model.dev.nvars;
     if (!smplx::load_mprim_text(mprim_text, params->resolutions, s->N, s->actions)) {
         const std::string err = s->actions.error;

@@ -27,28 +27,36 @@
 // small helpers
 // ---------------------------------------------------------------------------------------------
 
+// LDS pointers are declared in address space 3: 32-bit, always lowered to ds_* instructions, half the
+// scalar-register cost of generic pointers (the collision kernels are SGPR-bound).
+#define LDS_AS __attribute__((address_space(3)))
+typedef const LDS_AS SmplxJoint* JointPtr;
+typedef const LDS_AS SmplxNode* NodePtr;
+typedef const LDS_AS int* IntPtr;
+typedef const LDS_AS double* DblPtr;
+
 // The compiled model as the kernels see it: counts plus pointers into the LDS copy of the packed model
 // (device_types.h SMPLX_BH_*).  Field names match SmplxModelDev so the device code reads the same either way.
 struct ModelLds {
     int njoints, nvars, ntrees, nnodes, npairs, nslots, nroot;
-    const SmplxJoint* joints;
-    const SmplxNode* nodes;
-    const int *tree_first, *tree_joint, *tree_root_slot, *pair_first, *pair_other;
-    const double *var_min, *var_max, *var_min_norm, *var_k, *coord_delta;
-    const int *coord_vals, *var_type;
+    JointPtr joints;
+    NodePtr nodes;
+    IntPtr tree_first, tree_joint, tree_root_slot, pair_first, pair_other;
+    DblPtr var_min, var_max, var_min_norm, var_k, coord_delta;
+    IntPtr coord_vals, var_type;
 };
 
 struct ThreadLds {
-    const SmplxNode* nodes;   // shared: sphere trees
-    double* d;                // per-thread doubles, SoA: d[e * BLOCK + tid]
-    unsigned char* stk;       // per-thread byte stack, SoA
+    NodePtr nodes;            // shared: sphere trees
+    LDS_AS double* d;         // per-thread doubles, SoA: d[e * BLOCK + tid]
+    LDS_AS unsigned char* stk;   // per-thread byte stack, SoA
     int root_base;            // first double of root positions (3 per tree)
     int slot_base;            // first double of saved transforms (12 per slot)
     int q_base;               // first double of the configuration's joint values (one per planning variable)
 };
 
-__device__ __forceinline__ double& lds_d(const ThreadLds& L, int e) { return L.d[e * BLOCK + threadIdx.x]; }
-__device__ __forceinline__ unsigned char& lds_b(const ThreadLds& L, int e) { return L.stk[e * BLOCK + threadIdx.x]; }
+__device__ __forceinline__ LDS_AS double& lds_d(const ThreadLds& L, int e) { return L.d[e * BLOCK + threadIdx.x]; }
+__device__ __forceinline__ LDS_AS unsigned char& lds_b(const ThreadLds& L, int e) { return L.stk[e * BLOCK + threadIdx.x]; }
 
 // p = T * c   (robot_collision_state.h:576); ((a*x + b*y) + c*z) + t
 __device__ __forceinline__ void xform(const double T[12], const double c[3], double p[3])
@@ -59,9 +67,9 @@ __device__ __forceinline__ void xform(const double T[12], const double c[3], dou
 }
 
 // local transform of a joint: origin * R(q)   (transform_functions.h:95-258)
-__device__ __forceinline__ void joint_matrix(const SmplxJoint* __restrict__ j, double q, double J[12])
+__device__ __forceinline__ void joint_matrix(JointPtr j, double q, double J[12])
 {
-    const double* o = j->origin;
+    DblPtr o = j->origin;
     const int kind = j->kind;
     if (kind == SMPLX_TK_FIXED) {
 #pragma unroll
@@ -166,7 +174,7 @@ __device__ __forceinline__ bool check_tree(const ModelLds* __restrict__ M, const
     int sp = 0;
     int node = root;
     while (true) {
-        const SmplxNode& nd = L.nodes[node];
+        const LDS_AS SmplxNode& nd = L.nodes[node];
         double c[3] = {nd.c[0], nd.c[1], nd.c[2]};
         double p[3];
         xform(T, c, p);
@@ -230,7 +238,7 @@ __device__ __noinline__ void fk_two_links(const ModelLds* __restrict__ M, const 
     for (int i = 0; i < 12; ++i) T[i] = 0.0;
     const int last = ja > jb ? ja : jb;
     for (int j = 0; j <= last; ++j) {
-        const SmplxJoint* jt = &M->joints[j];
+        JointPtr jt = &M->joints[j];
         const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
         double J[12];
         joint_matrix(jt, q, J);
@@ -268,8 +276,8 @@ __device__ __noinline__ bool check_pair_full(const ModelLds* __restrict__ M, con
     int sp = 0;
     int na = M->tree_first[ta + 1] - 1, nb = M->tree_first[tb + 1] - 1;
     while (true) {
-        const SmplxNode& A = L.nodes[na];
-        const SmplxNode& B = L.nodes[nb];
+        const LDS_AS SmplxNode& A = L.nodes[na];
+        const LDS_AS SmplxNode& B = L.nodes[nb];
         double ca[3] = {A.c[0], A.c[1], A.c[2]}, cb[3] = {B.c[0], B.c[1], B.c[2]};
         double pa[3], pb[3];
         xform(Ta, ca, pa);
@@ -316,7 +324,7 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
     stage_config(M, L, e);
     const int nj = M->njoints;
     for (int j = 0; j < nj; ++j) {
-        const SmplxJoint* jt = &M->joints[j];
+        JointPtr jt = &M->joints[j];
         const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
         double J[12];
         joint_matrix(jt, q, J);
@@ -348,11 +356,11 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
             // anything the roots do not settle is queued and resolved after the chain (the slow path reuses the
             // transform slots).  A hit does not stop the voxel pass: the reference runs ALL voxel checks before
             // the first pair (self_collision_model.cpp:418-421), so lookup tallies stay identical.
-            const SmplxNode& B = L.nodes[M->tree_first[t + 1] - 1];
+            const LDS_AS SmplxNode& B = L.nodes[M->tree_first[t + 1] - 1];
             for (int k = M->pair_first[t]; k < M->pair_first[t + 1]; ++k) {
                 const int ta = M->pair_other[k];
                 const int sa = M->tree_root_slot[ta];
-                const SmplxNode& A = L.nodes[M->tree_first[ta + 1] - 1];
+                const LDS_AS SmplxNode& A = L.nodes[M->tree_first[ta + 1] - 1];
                 // pairs are stored (group-earlier, group-later); the subtraction order follows that
                 const bool a_first = ta < t;
                 const double ax = lds_d(L, L.root_base + 3 * sa + 0), ay = lds_d(L, L.root_base + 3 * sa + 1),
@@ -447,7 +455,7 @@ __device__ __forceinline__ void planning_fk(const ModelLds* __restrict__ M, cons
     bool first = true;
     const int nj = M->njoints;
     for (int j = 0; j < nj; ++j) {
-        const SmplxJoint* jt = &M->joints[j];
+        JointPtr jt = &M->joints[j];
         if (!jt->on_chain) continue;
         double qv = 0.0;
         if (jt->var >= 0) {
@@ -549,18 +557,19 @@ __device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict_
     M.njoints = hdr[SMPLX_BH_NJOINTS]; M.nvars = hdr[SMPLX_BH_NVARS]; M.ntrees = hdr[SMPLX_BH_NTREES];
     M.nnodes = hdr[SMPLX_BH_NNODES]; M.npairs = hdr[SMPLX_BH_NPAIRS]; M.nslots = hdr[SMPLX_BH_NSLOTS];
     M.nroot = hdr[SMPLX_BH_NROOT];
-    M.joints = reinterpret_cast<const SmplxJoint*>(smem + hdr[SMPLX_BH_OFF_JOINTS]);
-    M.nodes = reinterpret_cast<const SmplxNode*>(smem + hdr[SMPLX_BH_OFF_NODES]);
-    const int* ip = reinterpret_cast<const int*>(smem + hdr[SMPLX_BH_OFF_INTS]);
+    LDS_AS unsigned char* base = (LDS_AS unsigned char*)smem;
+    M.joints = (JointPtr)(base + hdr[SMPLX_BH_OFF_JOINTS]);
+    M.nodes = (NodePtr)(base + hdr[SMPLX_BH_OFF_NODES]);
+    IntPtr ip = (IntPtr)(base + hdr[SMPLX_BH_OFF_INTS]);
     M.tree_first = ip; ip += M.ntrees + 1;
     M.tree_joint = ip; ip += M.ntrees;
     M.tree_root_slot = ip; ip += M.ntrees;
     M.pair_first = ip; ip += M.ntrees + 1;
     M.pair_other = ip;
-    const double* dp = reinterpret_cast<const double*>(smem + hdr[SMPLX_BH_OFF_VARD]);
+    DblPtr dp = (DblPtr)(base + hdr[SMPLX_BH_OFF_VARD]);
     M.var_min = dp; M.var_max = dp + M.nvars; M.var_min_norm = dp + 2 * M.nvars; M.var_k = dp + 3 * M.nvars;
     M.coord_delta = dp + 4 * M.nvars;
-    const int* vp = reinterpret_cast<const int*>(smem + hdr[SMPLX_BH_OFF_VARI]);
+    IntPtr vp = (IntPtr)(base + hdr[SMPLX_BH_OFF_VARI]);
     M.coord_vals = vp; M.var_type = vp + M.nvars;
     return M;
 }
@@ -572,12 +581,12 @@ __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__
     *Mv = stage_model(S, smem);
     const int* hdr = reinterpret_cast<const int*>(S->model_blob);
     L.nodes = Mv->nodes;
-    L.d = reinterpret_cast<double*>(smem + hdr[SMPLX_BH_BYTES]);
+    L.d = (LDS_AS double*)((LDS_AS unsigned char*)smem + hdr[SMPLX_BH_BYTES]);
     L.root_base = 0;
     L.slot_base = 3 * Mv->nroot;
     L.q_base = 3 * Mv->nroot + 12 * Mv->nslots;
     const int nd = 3 * Mv->nroot + 12 * Mv->nslots + Mv->nvars;
-    L.stk = reinterpret_cast<unsigned char*>(L.d + (size_t)nd * BLOCK);
+    L.stk = (LDS_AS unsigned char*)(L.d + nd * BLOCK);
     __syncthreads();
     return L;
 }
@@ -1122,7 +1131,7 @@ k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict
     double T[12];
     for (int k = 0; k < 12; ++k) T[k] = 0.0;
     for (int j = 0; j < M->njoints; ++j) {
-        const SmplxJoint* jt = &M->joints[j];
+        JointPtr jt = &M->joints[j];
         double J[12];
         joint_matrix(jt, jt->var >= 0 ? q[jt->var] : 0.0, J);
         if (jt->src == SMPLX_SRC_ROOT) {

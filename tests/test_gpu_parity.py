@@ -279,3 +279,62 @@ def test_interleaved_multi_query_equals_each_query_alone(small_cfg, shared_scene
     assert sum(m["gpu_batches"] for m in multi) > 4
     if shared_scene:
         assert multi[1]["gpu_batches"] == 0 and multi[3]["gpu_batches"] == 0   # slice leaders (0 and 2) launched for their slices
+
+
+def test_deferred_pass_when_the_work_list_overflows(small_cfg):
+    """Edges whose waypoints do not fit the work list are resolved by the fused pass inside the same call
+    (SMPLX_F_DEFERRED never leaks out); results identical to the oracle."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    o = Oracle(small_cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(small_cfg, tiny_work_list=True)
+    s.fused = False
+    o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    Q = np.vstack([np.array(small_cfg.start), _random_states(200, 41)])
+    got = s.expand_batch(Q)
+    assert not (got["flags"] & 0x80).any()
+    for i, q in enumerate(Q):
+        exp = o.eval_state(q)
+        assert np.array_equal(exp["flags"], got["flags"][i])
+        v = (exp["flags"] & 1) != 0
+        assert np.array_equal(exp["coord"][v], got["coord"][i][v]) and np.array_equal(exp["h"][v], got["h"][i][v])
+
+
+def test_edge_cases_empty_batches_bad_start_and_goal_outside_grid(small_cfg):
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = small_cfg
+    s = capi.Space.from_config(cfg)
+    # empty batches are fine and touch nothing
+    ok, lk = s.state_valid_batch(np.zeros((0, 7)))
+    assert ok.shape == (0,)
+    e, _, _ = s.edge_valid_batch(np.zeros((0, 7)), np.zeros((0, 7)))
+    assert e.shape == (0,)
+    # expansion needs a goal (the primitives are gated by goal distance): call-sequence error, not a crash
+    with pytest.raises(capi.SmplxError) as err:
+        s.expand_batch(np.array([cfg.start]))
+    assert err.value.code == -5
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert s.expand_batch(np.zeros((0, 7)))["flags"].shape == (0, 25)
+    # a start state outside the joint limits / in collision is refused like ManipLattice::setStart (:1956-1967)
+    bad = np.array(cfg.start); bad[3] = 0.5
+    with pytest.raises(capi.SmplxError) as err:
+        s.set_start(bad)
+    assert err.value.code == -6
+    coll = scenes.random_states(scenes.ARM7_LIMITS, 400, 51)
+    okc, _ = s.state_valid_batch(coll)
+    with pytest.raises(capi.SmplxError) as err:
+        s.set_start(coll[np.argmin(okc)])
+    assert err.value.code == -6
+    # goal position outside the grid: BFS_3D::run labels nothing (bfs3d.cpp:169-171), every heuristic is
+    # cost_per_cell * UNDISCOVERED(-1) or Infinity for walls -- same as the oracle
+    o = Oracle(cfg)
+    far = [cfg.grid.origin[0] - 1.0, 0.0, 1.0]
+    o.set_goal_xyz(far, [0.04] * 3); s.set_goal_xyz(far, [0.04] * 3)
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+    Q = _random_states(50, 52)
+    h, _ = s.heuristic_batch(Q)
+    assert np.array_equal(h, np.array([o.heuristic_q(q) for q in Q]))
+    assert set(np.unique(h)) <= {-cfg.params.cost_per_cell, 32767}
