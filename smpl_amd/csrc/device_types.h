@@ -16,7 +16,10 @@
 
 // joint transform kinds (sbpl_collision_checking/src/transform_functions.h:95-258)
 enum { SMPLX_TK_FIXED = 0, SMPLX_TK_REV_X = 1, SMPLX_TK_REV_Y = 2, SMPLX_TK_REV_Z = 3, SMPLX_TK_REV_GENERIC = 4,
-       SMPLX_TK_PRISMATIC = 5 };
+       SMPLX_TK_PRISMATIC = 5,
+       // the same joints when the origin's rotation is exactly the identity: the products with 0 and 1 are skipped,
+       // every non-zero result is bit-identical to the general form
+       SMPLX_TK_FIXED_T = 6, SMPLX_TK_REV_X_T = 7, SMPLX_TK_REV_Y_T = 8, SMPLX_TK_REV_Z_T = 9 };
 // joint types
 enum { SMPLX_JT_FIXED = 0, SMPLX_JT_REVOLUTE = 1, SMPLX_JT_CONTINUOUS = 2, SMPLX_JT_PRISMATIC = 3 };
 // where a joint's parent-link transform comes from in the depth-first joint list

@@ -146,6 +146,57 @@ __device__ __forceinline__ void mul_affine(double T[12], const double J[12])
     for (int i = 0; i < 12; ++i) T[i] = R[i];
 }
 
+// One step of the kinematic chain: T = T * J(q), or T = J(q) for a joint on the root link.
+// For origins whose rotation is exactly the identity (SMPLX_TK_*_T) the general form
+//   J = origin * R_axis(q)   (transform_functions.h:104-207),   T' = T * J   (robot_collision_state.h:419-421)
+// multiplies by 0 and 1 only; the terms x*1 and y*0 are exact, adding +-0 changes no non-zero value, and
+// a*(-s) + b*c == b*c - a*s bit for bit, so the shortened expressions below give identical bits.
+__device__ __forceinline__ void apply_joint(JointPtr jt, double q, double T[12], bool on_root)
+{
+    const int kind = jt->kind;
+    if (kind < SMPLX_TK_FIXED_T) {
+        double J[12];
+        joint_matrix(jt, q, J);
+        if (on_root) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = J[i];
+        } else {
+            mul_affine(T, J);
+        }
+        return;
+    }
+    DblPtr o = jt->origin;
+    const double tx = o[3], ty = o[7], tz = o[11];
+    if (on_root) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = 0.0;
+        T[0] = 1.0; T[5] = 1.0; T[10] = 1.0;
+        T[3] = tx; T[7] = ty; T[11] = tz;
+        if (kind == SMPLX_TK_FIXED_T) return;
+        double s, c;
+        smplx_sincos(q, &s, &c);
+        if (kind == SMPLX_TK_REV_X_T) { T[5] = c; T[6] = 0.0 - s; T[9] = s; T[10] = c; }
+        else if (kind == SMPLX_TK_REV_Y_T) { T[0] = c; T[2] = s; T[8] = 0.0 - s; T[10] = c; }
+        else { T[0] = c; T[1] = 0.0 - s; T[4] = s; T[5] = c; }
+        return;
+    }
+    // translation first: it uses the rotation of T before it is rotated
+    const double n3 = ((T[0] * tx + T[1] * ty) + T[2] * tz) + T[3];
+    const double n7 = ((T[4] * tx + T[5] * ty) + T[6] * tz) + T[7];
+    const double n11 = ((T[8] * tx + T[9] * ty) + T[10] * tz) + T[11];
+    T[3] = n3; T[7] = n7; T[11] = n11;
+    if (kind == SMPLX_TK_FIXED_T) return;
+    double s, c;
+    smplx_sincos(q, &s, &c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a = T[4 * i + 0], b = T[4 * i + 1], d = T[4 * i + 2];
+        if (kind == SMPLX_TK_REV_X_T) { T[4 * i + 1] = b * c + d * s; T[4 * i + 2] = d * c - b * s; }
+        else if (kind == SMPLX_TK_REV_Y_T) { T[4 * i + 0] = a * c - d * s; T[4 * i + 2] = a * s + d * c; }
+        else { T[4 * i + 0] = a * c + b * s; T[4 * i + 1] = b * c - a * s; }
+    }
+}
+
 // voxel lookup: squared cell distance at a world point, 0 outside the grid
 // (occupancy_grid.h:234 -> distance_map.hpp:281-300, 520-536)
 __device__ __forceinline__ int grid_d2(const SmplxGridDev& g, const double p[3])
@@ -240,18 +291,11 @@ __device__ __noinline__ void fk_two_links(const ModelLds* __restrict__ M, const 
     for (int j = 0; j <= last; ++j) {
         JointPtr jt = &M->joints[j];
         const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
-        double J[12];
-        joint_matrix(jt, q, J);
-        if (jt->src == SMPLX_SRC_ROOT) {
+        if (jt->src >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = J[i];
-        } else {
-            if (jt->src >= 0) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
-            }
-            mul_affine(T, J);
+            for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
         }
+        apply_joint(jt, q, T, jt->src == SMPLX_SRC_ROOT);
         if (jt->save_slot >= 0) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * jt->save_slot + i) = T[i];
@@ -326,18 +370,11 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
     for (int j = 0; j < nj; ++j) {
         JointPtr jt = &M->joints[j];
         const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
-        double J[12];
-        joint_matrix(jt, q, J);
-        if (jt->src == SMPLX_SRC_ROOT) {
+        if (jt->src >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = J[i];
-        } else {
-            if (jt->src >= 0) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
-            }
-            mul_affine(T, J);
+            for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
         }
+        apply_joint(jt, q, T, jt->src == SMPLX_SRC_ROOT);
         if (jt->save_slot >= 0) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * jt->save_slot + i) = T[i];
@@ -462,15 +499,8 @@ __device__ __forceinline__ void planning_fk(const ModelLds* __restrict__ M, cons
             qv = q[jt->var];
             if (M->var_type[jt->var] == SMPLX_JT_CONTINUOUS) qv = smplx_normalize_angle(qv);
         }
-        double J[12];
-        joint_matrix(jt, qv, J);
-        if (first) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = J[i];
-            first = false;
-        } else {
-            mul_affine(T, J);
-        }
+        apply_joint(jt, qv, T, first);
+        first = false;
     }
     p[0] = T[3]; p[1] = T[7]; p[2] = T[11];
 }
@@ -1132,14 +1162,8 @@ k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict
     for (int k = 0; k < 12; ++k) T[k] = 0.0;
     for (int j = 0; j < M->njoints; ++j) {
         JointPtr jt = &M->joints[j];
-        double J[12];
-        joint_matrix(jt, jt->var >= 0 ? q[jt->var] : 0.0, J);
-        if (jt->src == SMPLX_SRC_ROOT) {
-            for (int k = 0; k < 12; ++k) T[k] = J[k];
-        } else {
-            if (jt->src >= 0) for (int k = 0; k < 12; ++k) T[k] = lds_d(L, L.slot_base + 12 * jt->src + k);
-            mul_affine(T, J);
-        }
+        if (jt->src >= 0) for (int k = 0; k < 12; ++k) T[k] = lds_d(L, L.slot_base + 12 * jt->src + k);
+        apply_joint(jt, jt->var >= 0 ? q[jt->var] : 0.0, T, jt->src == SMPLX_SRC_ROOT);
         if (jt->save_slot >= 0) for (int k = 0; k < 12; ++k) lds_d(L, L.slot_base + 12 * jt->save_slot + k) = T[k];
         if (jt->tree >= 0) {
             for (int nd = M->tree_first[jt->tree]; nd < M->tree_first[jt->tree + 1]; ++nd) {

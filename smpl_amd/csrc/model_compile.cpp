@@ -377,6 +377,17 @@ bool compile_robot_text(const char* text, HostModel& m)
             else if (a[0] == 0.0 && a[1] == 1.0 && a[2] == 0.0) J.kind = SMPLX_TK_REV_Y;
             else if (a[0] == 0.0 && a[1] == 0.0 && a[2] == 1.0) J.kind = SMPLX_TK_REV_Z;
             else J.kind = SMPLX_TK_REV_GENERIC;
+            {   // identity origin rotation (rpy = 0; -0.0 counts as 0): translation-only forms of the same transforms
+                const double* o = J.origin;
+                const bool ident = o[0] == 1.0 && o[1] == 0.0 && o[2] == 0.0 && o[4] == 0.0 && o[5] == 1.0 && o[6] == 0.0 &&
+                                   o[8] == 0.0 && o[9] == 0.0 && o[10] == 1.0;
+                if (ident) {
+                    if (J.kind == SMPLX_TK_FIXED) J.kind = SMPLX_TK_FIXED_T;
+                    else if (J.kind == SMPLX_TK_REV_X) J.kind = SMPLX_TK_REV_X_T;
+                    else if (J.kind == SMPLX_TK_REV_Y) J.kind = SMPLX_TK_REV_Y_T;
+                    else if (J.kind == SMPLX_TK_REV_Z) J.kind = SMPLX_TK_REV_Z_T;
+                }
+            }
             J.var = -1;
             J.src = is_root ? SMPLX_SRC_ROOT : (c == 0 ? SMPLX_SRC_RUNNING : my_slot);
             J.save_slot = -1;
