@@ -254,23 +254,16 @@ struct EdgeRef {
 };
 
 // joint values of the configuration on the edge at parameter alpha
-// (robot_motion_collision_model.h:221-247 diffs, 297-320 interpolate), staged into per-thread LDS with every
-// global load issued before the first use: the FK loop then never waits on HBM for a joint value
+// (robot_motion_collision_model.h:221-247 diffs, 297-320 interpolate), staged into per-thread LDS once per
+// configuration (the slow path of the sphere-sphere pass re-reads them)
 __device__ __forceinline__ void stage_config(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e)
 {
     const int nv = M->nvars;
-    double sv[SMPLX_MAX_VARS], fv[SMPLX_MAX_VARS];
-#pragma unroll
-    for (int v = 0; v < SMPLX_MAX_VARS; ++v) {
-        if (v < nv) { sv[v] = e.start[v]; fv[v] = e.finish[v]; }
-    }
-#pragma unroll
-    for (int v = 0; v < SMPLX_MAX_VARS; ++v) {
-        if (v < nv) {
-            double q = sv[v];
-            if (e.alpha != 0.0) q = sv[v] + e.alpha * edge_diff(M, v, sv[v], fv[v]);   // start + 0*diff == start exactly
-            lds_d(L, L.q_base + v) = q;
-        }
+    for (int v = 0; v < nv; ++v) {
+        const double sv = e.start[v];
+        double q = sv;
+        if (e.alpha != 0.0) q = sv + e.alpha * edge_diff(M, v, sv, e.finish[v]);   // start + 0*diff == start exactly
+        lds_d(L, L.q_base + v) = q;
     }
 }
 
@@ -281,7 +274,7 @@ __device__ __forceinline__ double config_var(const ModelLds* __restrict__ M, con
 }
 
 // link transforms of two trees' links for one configuration (slow path of the sphere-sphere pass)
-__device__ __noinline__ void fk_two_links(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+__device__ __forceinline__ void fk_two_links(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
                                           int ja, int jb, double Ta[12], double Tb[12])
 {
     double T[12];
@@ -312,7 +305,7 @@ __device__ __noinline__ void fk_two_links(const ModelLds* __restrict__ M, const 
 }
 
 // sphere tree vs sphere tree (self_collision_model.cpp:1093-1218); false = collision
-__device__ __noinline__ bool check_pair_full(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+__device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
                                              int ta, int tb)
 {
     double Ta[12], Tb[12];
@@ -419,20 +412,23 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
             }
         }
     }
-    if (recheck_all) {
-        for (int t = 0; t < M->ntrees && !pair_hit; ++t)
-            for (int k = M->pair_first[t]; k < M->pair_first[t + 1] && !pair_hit; ++k) {
-                const int ta = M->pair_other[k];
-                const int a = ta < t ? ta : t, b = ta < t ? t : ta;
-                if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
-            }
-    } else {
-        for (int i = 0; i < npending && !pair_hit; ++i) {
+    // unresolved pairs (normally none): one call site for the slow path, so it can be inlined without
+    // putting the model view into scratch memory
+    const int total = recheck_all ? M->pair_first[M->ntrees] : npending;
+    int tcur = 0;
+    for (int i = 0; i < total && !pair_hit; ++i) {
+        int ta, t;
+        if (recheck_all) {
+            while (i >= M->pair_first[tcur + 1]) ++tcur;
+            t = tcur;
+            ta = M->pair_other[i];
+        } else {
             const int code = (int)((pending >> (16 * i)) & 0xFFFF);
-            const int ta = code >> 8, t = code & 0xFF;
-            const int a = ta < t ? ta : t, b = ta < t ? t : ta;
-            if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
+            ta = code >> 8;
+            t = code & 0xFF;
         }
+        const int a = ta < t ? ta : t, b = ta < t ? t : ta;
+        if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
     }
     return !pair_hit;
 }
