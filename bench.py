@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--planner-expansions", type=int, default=40000)
     ap.add_argument("--multi-queries", type=int, default=32, help="queries interleaved on one GPU in the planner leg")
     ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the planner_multi leg")
+    ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     args = ap.parse_args()
@@ -188,6 +189,34 @@ def main():
         "valid_fraction": round(valid / max(evals, 1), 4),
         "roofline": roofline,
     }
+
+    if rank == 0 and world == 1 and args.overlap_streams > 1:
+        # secondary figure: the same step with several independent frontier batches in flight (what a GPU that
+        # serves many queries sees); each in-flight batch has its own buffers and stream.  Not `value`.
+        S_ = args.overlap_streams
+        streams = [torch.cuda.Stream() for _ in range(S_)]
+        sets = []
+        for _ in range(S_):
+            sets.append(dict(flags=torch.zeros_like(d_flags), coord=torch.zeros_like(d_coord), sq=torch.zeros_like(d_sq),
+                             h=torch.zeros_like(d_h), cost=torch.zeros_like(d_cost), lk=torch.zeros_like(d_lk),
+                             work=torch.zeros_like(d_work), cnt=torch.zeros_like(d_cnt)))
+
+        def step_on(i):
+            b = sets[i % S_]
+            space.expand_batch_device(d_q.data_ptr(), B, b["flags"].data_ptr(), b["coord"].data_ptr(), b["sq"].data_ptr(),
+                                      b["h"].data_ptr(), b["cost"].data_ptr(), b["lk"].data_ptr(), b["work"].data_ptr(),
+                                      b["cnt"].data_ptr(), streams[i % S_].cuda_stream)
+        for i in range(S_):
+            step_on(i)
+        torch.cuda.synchronize()
+        nst = args.steps * S_
+        t0o = time.perf_counter()
+        for i in range(nst):
+            step_on(i)
+        torch.cuda.synchronize()
+        t1o = time.perf_counter()
+        out["overlapped"] = {"streams": S_, "steps": nst, "ms_per_step": round(1e3 * (t1o - t0o) / nst, 4),
+                             "successor_evaluations_per_s": round(evals / max(launches, 1) * nst / (t1o - t0o), 1)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
