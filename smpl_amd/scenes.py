@@ -289,6 +289,28 @@ def config2(n: int = 256, nboxes: int = 64, seed: int = 2) -> Config:
                   [3.0 * DEG] * 7, boxes)
 
 
+def config3(n: int = 150, nclutter: int = 20, seed: int = 3) -> Config:
+    """SURVEY 8d cfg 3: PR2-right-arm-like model as data, 150^3 @ 0.02 m, origin (-0.75,-1.5,0), max_dist 1.8
+    (smpl_test/src/call_planner.cpp:1587-1594), cluttered tabletop (seed 3); base and torso enter the grid as
+    static boxes (in the reference they are voxelised out-of-group links).  The grid is not a multiple of the
+    4-cell brick and squared distances reach 8100."""
+    res = 0.02
+    origin = (-0.75, -1.5, 0.0)
+    rng = np.random.default_rng(seed)
+    boxes = [TABLETOP, ((-0.05, 0.0, 0.18), (0.65, 0.65, 0.36)), ((-0.32, 0.0, 0.62), (0.3, 0.35, 0.5))]
+    while len(boxes) < 3 + nclutter:       # clutter standing on the table
+        e = rng.uniform(0.04, 0.12, size=3)
+        c = (0.35 + rng.uniform(0.05, 0.35), rng.uniform(-0.7, 0.7), 0.61 + 0.5 * e[2])
+        if abs(c[1] + 0.188) < 0.25 and c[0] < 0.6:
+            continue                       # keep the corridor in front of the shoulder free
+        boxes.append((tuple(c), tuple(e)))
+    grid = build_grid(origin, (n, n, n), res, 1.8, boxes)
+    p = PlanningParams([DEG] * 7, eps0=100.0)     # call_planner.cpp:1727-1729
+    goal = [ARM7_START[i] + c * DEG for i, c in enumerate([-49, 7, 21, -14, -8, -12, 16])]
+    return Config("cfg3", arm7_robot(), mprim_text(7, range(4), range(7)), grid, p, list(ARM7_START), goal,
+                  [3.0 * DEG] * 7, boxes)
+
+
 def config_small(n: int = 64, seed: int = 7, nboxes: int = 6) -> Config:
     """Small test scene (64^3 @ 0.04 m): the oracle finishes a full ARA* query in well under a second."""
     res = 0.04

@@ -338,3 +338,27 @@ def test_edge_cases_empty_batches_bad_start_and_goal_outside_grid(small_cfg):
     h, _ = s.heuristic_batch(Q)
     assert np.array_equal(h, np.array([o.heuristic_q(q) for q in Q]))
     assert set(np.unique(h)) <= {-cfg.params.cost_per_cell, 32767}
+
+
+def test_config3_pr2_like_cluttered_tabletop():
+    """SURVEY cfg 3: 150^3 grid (not a multiple of the 4-cell brick), max_dist 1.8 m (squared cell distances up to
+    8100 in 16 bits), clutter on the table, eps 100."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = scenes.config3()
+    assert cfg.grid.d2.max() > 400
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg, batch_states=1024)
+    s.fused = False
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+    _compare_expand(o, s, np.vstack([np.array(cfg.start), _random_states(80, 61)]))
+    o.set_order(chain=False)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    o.search_params(100.0, 1.0, 1.0, True, True, 2500, 2500)
+    eo = o.plan()
+    go = s.plan(100.0, 1.0, 1.0, True, True, 2500, 2500)
+    assert eo["ok"] == go["solved"] and eo["cost"] == go["cost"]
+    assert np.array_equal(eo["expansion_log"], go["expansion_log"])
