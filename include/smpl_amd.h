@@ -84,7 +84,8 @@ typedef struct smplx_params {
                                          reference's waypoint order (exact reference lookup tallies);
                                          default 0: waypoint-parallel pipeline (same results, faster);
                                          bit 1: test hook -- a tiny work list, so that most edges take the
-                                         deferred (fused) pass of the pipeline */
+                                         deferred (fused) pass of the pipeline; bit 2: never use the single-launch
+                                         kernel for small batches (<= 256 states) */
 } smplx_params;
 
 /* RobotPlanningSpace::init + insertHeuristic (smpl/include/smpl/graph/robot_planning_space.h:68,89;

@@ -163,7 +163,7 @@ class Space:
     """ManipLattice + BfsHeuristic + CollisionSpace for one query, on one GPU."""
 
     def __init__(self, model: Model, grid: Grid, mprim_text: str, params, batch_states: int = 0, fused: bool = False,
-                 tiny_work_list: bool = False):
+                 tiny_work_list: bool = False, no_small_kernel: bool = False):
         self.model, self.grid = model, grid
         P = Params()
         for i, r in enumerate(params.resolutions):
@@ -178,14 +178,15 @@ class Space:
         P.use_long_and_short = int(params.use_long_and_short)
         P.padding = 0.0
         P.batch_states = batch_states
-        P.reserved = (1 if fused else 0) | (2 if tiny_work_list else 0)
+        P.reserved = (1 if fused else 0) | (2 if tiny_work_list else 0) | (4 if no_small_kernel else 0)
         self.h = C.c_void_p()
         _chk(lib().smplx_space_create(model.h, grid.h, mprim_text.encode(), C.byref(P), C.byref(self.h)))
         self.N = lib().smplx_space_num_vars(self.h)
         self.M = lib().smplx_space_num_prims(self.h)
 
     @classmethod
-    def from_config(cls, cfg, batch_states: int = 0, xy_rotate=None, fused: bool = False, tiny_work_list: bool = False):
+    def from_config(cls, cfg, batch_states: int = 0, xy_rotate=None, fused: bool = False, tiny_work_list: bool = False,
+                    no_small_kernel: bool = False):
         g = Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
         m = Model(cfg.robot_text)
         p = cfg.params
@@ -193,7 +194,7 @@ class Space:
             import copy
             p = copy.copy(p)
             p.xy_rotate_by_var3 = xy_rotate
-        return cls(m, g, cfg.mprim, p, batch_states, fused, tiny_work_list)
+        return cls(m, g, cfg.mprim, p, batch_states, fused, tiny_work_list, no_small_kernel)
 
     def close(self):
         if self.h:

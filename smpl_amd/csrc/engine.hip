@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -155,6 +156,7 @@ struct smplx_space {
     int32_t* d_bfs = nullptr;
     int32_t* d_queue[2] = {nullptr, nullptr};
     int32_t* d_counts = nullptr;
+    int32_t* d_minus_one = nullptr;   // a device int holding -1 (k_expand: deferred pass without a counter)
     int64_t bfs_total = 0;
     int bfs_levels = 0;
     int wall_thr = -1;
@@ -166,6 +168,7 @@ struct smplx_space {
     DevBuf<int32_t> b_coord, b_h, b_cost, b_lookups, b_way;
     bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
     bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
+    int small_batch_max = 256;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
     DevBuf<unsigned long long> b_counters;
     PinBuf<double> p_q, p_sq;
     PinBuf<unsigned char> p_flags;
@@ -191,6 +194,7 @@ struct smplx_space {
     // a frontier batch in flight (issued on `stream`, completion signalled by `batch_done`)
     std::vector<int32_t> inflight;
     hipEvent_t batch_done = nullptr;
+    bool inflight_zero_copy = false;   // the batch in flight wrote its results straight into the pinned host buffers
     // stats
     int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0, gpu_evals = 0;
     // cross-query batches (smplx_plan_multi): query table + per-state query index, owned by the leading space
@@ -341,7 +345,8 @@ ExpandWork carve_work(void* base, int B, int M)
 
 int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
-                  hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr)
+                  hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr,
+                  const smplx_space* zero_copy = nullptr)
 {
     ExpandWork k = carve_work(d_work, B, s->M);
     if (s->tiny_work_list) k.capacity = 8 * 16;   // test hook: almost every edge overflows into the deferred pass
@@ -350,7 +355,21 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int bs = blocks_for(B, SMPLX_BLOCK);
     const int be = blocks_for((long long)B * s->M, SMPLX_BLOCK);
     const int64_t* norefs = nullptr;
-    if (s->fused_mode) {
+    const int small_block = smplx_small_block(s->M);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    if (!s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list) {
+        // a handful of states: one launch, all FK chains side by side (kernels.hip k_small_batch)
+        const int32_t* deferred = s->d_minus_one;   // "no counter": the deferred pass scans its own flags
+        // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
+        const double* qsrc = zero_copy ? zero_copy->p_q.p : d_q;
+        hipLaunchKernelGGL(k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
+                           k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
+                           zero_copy ? zero_copy->p_flags.p : (unsigned char*)nullptr, zero_copy ? zero_copy->p_coord.p : (int32_t*)nullptr,
+                           zero_copy ? zero_copy->p_sq.p : (double*)nullptr, zero_copy ? zero_copy->p_h.p : (int32_t*)nullptr);
+        hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, qsrc, norefs, B,
+                           k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
+                           d_counters, (const int*)deferred, stab, state_q);
+    } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (ev) (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
@@ -454,6 +473,26 @@ void select_batch(smplx_space* s, int id, int cap)
     s->hint.clear();
 }
 
+// A frontier batch takes tens of microseconds; an interrupt-driven hipEventSynchronize adds about as much again to
+// wake the thread up.  The search thread has nothing else to do, so it polls.
+int wait_event_polling(hipEvent_t ev)
+{
+    while (true) {
+        const hipError_t st = hipEventQuery(ev);
+        if (st == hipSuccess) return SMPLX_OK;
+        if (st != hipErrorNotReady) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+    }
+}
+
+// small batches skip the DMA copies: the kernel reads the parents from, and writes the results to, pinned host memory
+bool takes_small_kernel(const smplx_space* s, int B)
+{
+    const int small_block = smplx_small_block(s->M);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    return !s->fused_mode && s->prof_events.empty() && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
+           !s->tiny_work_list;
+}
+
 // enqueue one frontier batch (state `id` plus hinted frontier states) on the space's stream: upload, the
 // expansion pipeline, download, completion event.  Returns without waiting.
 int issue_batch(smplx_space* s, int id)
@@ -472,6 +511,14 @@ int issue_batch(smplx_space* s, int id)
     if ((e = s->p_sq.reserve(BM * N))) return e;
     if ((e = s->p_h.reserve(BM))) return e;
     for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
+    s->inflight_zero_copy = takes_small_kernel(s, B);
+    if (s->inflight_zero_copy) {
+        if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
+                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, s))) return e;
+        HIP_TRY(hipEventRecord(s->batch_done, s->stream));
+        ++s->gpu_batches;
+        return SMPLX_OK;
+    }
     HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * B * N, hipMemcpyHostToDevice, s->stream));
     if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
                            s->b_work.p, s->b_counters.p, s->stream))) return e;
@@ -491,6 +538,20 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
     const int N = s->N, M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
+    if (src == s && s->inflight_zero_copy) {
+        // edges too long for the single-launch kernel were finished by the deferred pass in device memory only:
+        // fetch the device copies in that (rare) case
+        const size_t BM = (size_t)B * M;
+        bool deferred = false;
+        for (size_t k = 0; k < BM && !deferred; ++k) deferred = (s->p_flags.p[k] & SMPLX_F_DEFERRED) != 0;
+        if (deferred) {
+            HIP_TRY(hipMemcpy(s->p_flags.p, s->b_flags.p, BM, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(s->p_h.p, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(s->p_coord.p, s->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(s->p_sq.p, s->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost));
+        }
+        s->inflight_zero_copy = false;
+    }
     for (int i = 0; i < B; ++i) {
         const int sid = batch[i];
         s->cache_off[sid] = (int64_t)s->recs.size();
@@ -520,7 +581,7 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
 int run_batch(smplx_space* s, int id)
 {
     if (int e = issue_batch(s, id)) return e;
-    HIP_TRY(hipEventSynchronize(s->batch_done));
+    if (int e = wait_event_polling(s->batch_done)) return e;
     return collect_batch(s);
 }
 
@@ -687,6 +748,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->params = *params;
     s->fused_mode = (params->reserved & 1) != 0;
     s->tiny_work_list = (params->reserved & 2) != 0;
+    if (params->reserved & 4) s->small_batch_max = 0;
     s->N = s->model.dev.nvars;
     if (!smplx::load_mprim_text(mprim_text, params->resolutions, s->N, s->actions)) {
         const std::string err = s->actions.error;
@@ -733,6 +795,8 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if ((e = hipMalloc((void**)&s->d_queue[0], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
     if ((e = hipMalloc((void**)&s->d_queue[1], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
     if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * 4)) != hipSuccess) return bail(e, "hipMalloc bfs counts");
+    if ((e = hipMalloc((void**)&s->d_minus_one, sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc");
+    { const int32_t m1 = -1; if ((e = hipMemcpy(s->d_minus_one, &m1, sizeof(m1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy"); }
     s->hs.bfs.dim_x = dx; s->hs.bfs.dim_y = dy; s->hs.bfs.dim_z = dz; s->hs.bfs.dim_xy = dx * dy;
     s->hs.bfs.cost_per_cell = params->cost_per_cell;
     s->hs.bfs.dist = s->d_bfs;
@@ -756,6 +820,7 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_queue[0]) (void)hipFree(s->d_queue[0]);
     if (s->d_queue[1]) (void)hipFree(s->d_queue[1]);
     if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1476,6 +1541,10 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
     } else {
         // One host thread drives every query: a query runs until it misses, its frontier batch goes to its own
         // stream, and the thread moves on to the next query; a landed batch is collected when its turn comes again.
+        double t_resume = 0, t_wait = 0, t_collect = 0;
+        const bool dbg = getenv("SMPLX_DEBUG_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         while (remaining > 0) {
             bool progressed = false;
             for (int q = 0; q < nq; ++q) {
@@ -1485,10 +1554,14 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
                     const hipError_t st = hipEventQuery(s->batch_done);
                     if (st == hipErrorNotReady) continue;
                     if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+                    const auto c0 = now();
                     if (int e = collect_batch(s)) return e;
+                    t_collect += secs(c0, now());
                     waiting[q] = 0;
                 }
+                const auto r0 = now();
                 const int r = S[q].resume();
+                t_resume += secs(r0, now());
                 progressed = true;
                 if (S[q].error) return S[q].error;
                 if (r == Search::R_YIELD) { waiting[q] = 1; continue; }
@@ -1498,10 +1571,13 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
             }
             if (!progressed) {
                 // every live query is waiting on the GPU: block on one of them instead of spinning
+                const auto w0 = now();
                 for (int q = 0; q < nq; ++q)
-                    if (!done[q] && waiting[q]) { HIP_TRY(hipEventSynchronize(spaces[q]->batch_done)); break; }
+                    if (!done[q] && waiting[q]) { if (int e = wait_event_polling(spaces[q]->batch_done)) return e; break; }
+                t_wait += secs(w0, now());
             }
         }
+        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs\n", t_resume, t_wait, t_collect);
     }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (wall_seconds) *wall_seconds = wall;

@@ -11,6 +11,12 @@
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
 // dynamic LDS bytes: the packed model, plus (collision kernels) per-thread scratch
+// small-batch kernel: 8 lanes per primitive + 2 state-level threads, rounded up to whole waves
+static inline int smplx_small_block(int nprims) { return ((nprims * 8 + 2) + 63) / 64 * 64; }
+static inline size_t smplx_lds_bytes_n(size_t blob_bytes, int nroot, int nslots, int nvars, int nthreads)
+{
+    return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * nthreads + (size_t)SMPLX_STACK_BYTES * nthreads;
+}
 static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots, int nvars)
 {
     return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * SMPLX_BLOCK + (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
@@ -41,6 +47,11 @@ __global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int
                               const unsigned char* state_bad, unsigned char* out_flags, int* out_coord, double* out_q,
                               int* out_h, int* out_cost, int* out_lookups, unsigned long long* counters,
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q);
+__global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist_out,
+                              unsigned char* state_bad_out, int* state_lookups_out, unsigned char* out_flags, int* out_coord,
+                              double* out_q, int* out_h, int* out_cost, int* out_lookups, int* deferred_count,
+                              const SmplxSpaceDev* const* stab, const unsigned short* state_q, unsigned char* host_flags,
+                              int* host_coord, double* host_q, int* host_h);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

@@ -53,10 +53,11 @@ struct ThreadLds {
     int root_base;            // first double of root positions (3 per tree)
     int slot_base;            // first double of saved transforms (12 per slot)
     int q_base;               // first double of the configuration's joint values (one per planning variable)
+    int stride;               // threads per block (SoA stride)
 };
 
-__device__ __forceinline__ LDS_AS double& lds_d(const ThreadLds& L, int e) { return L.d[e * BLOCK + threadIdx.x]; }
-__device__ __forceinline__ LDS_AS unsigned char& lds_b(const ThreadLds& L, int e) { return L.stk[e * BLOCK + threadIdx.x]; }
+__device__ __forceinline__ LDS_AS double& lds_d(const ThreadLds& L, int e) { return L.d[e * L.stride + threadIdx.x]; }
+__device__ __forceinline__ LDS_AS unsigned char& lds_b(const ThreadLds& L, int e) { return L.stk[e * L.stride + threadIdx.x]; }
 
 // p = T * c   (robot_collision_state.h:576); ((a*x + b*y) + c*z) + t
 __device__ __forceinline__ void xform(const double T[12], const double c[3], double p[3])
@@ -560,7 +561,7 @@ __device__ __forceinline__ int var_to_coord(const ModelLds* __restrict__ M, int 
 // Cooperative copy of the packed model (a few KB) into LDS in 16-byte pieces, all loads of a thread issued before
 // its first store; every later read of the model is a uniform-address LDS broadcast instead of a dependent
 // global load.  Returns the view.
-__device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict__ S, unsigned char* smem)
+__device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict__ S, unsigned char* smem, int nthreads = BLOCK)
 {
     typedef double __attribute__((ext_vector_type(2))) d2_t;
     const int* hdr = reinterpret_cast<const int*>(S->model_blob);
@@ -570,15 +571,15 @@ __device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict_
     d2_t v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int i = threadIdx.x + k * BLOCK;
+        const int i = threadIdx.x + k * nthreads;
         if (i < total) v[k] = src[i];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int i = threadIdx.x + k * BLOCK;
+        const int i = threadIdx.x + k * nthreads;
         if (i < total) dst[i] = v[k];
     }
-    for (int i = threadIdx.x + 4 * BLOCK; i < total; i += BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x + 4 * nthreads; i < total; i += nthreads) dst[i] = src[i];
     ModelLds M;
     M.njoints = hdr[SMPLX_BH_NJOINTS]; M.nvars = hdr[SMPLX_BH_NVARS]; M.ntrees = hdr[SMPLX_BH_NTREES];
     M.nnodes = hdr[SMPLX_BH_NNODES]; M.npairs = hdr[SMPLX_BH_NPAIRS]; M.nslots = hdr[SMPLX_BH_NSLOTS];
@@ -601,10 +602,12 @@ __device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict_
 }
 
 // model + per-thread scratch (root-position slots, saved transforms, DFS stack)
-__device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__ S, unsigned char* smem, ModelLds* Mv)
+__device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__ S, unsigned char* smem, ModelLds* Mv,
+                                               int nthreads = BLOCK)
 {
     ThreadLds L;
-    *Mv = stage_model(S, smem);
+    *Mv = stage_model(S, smem, nthreads);
+    L.stride = nthreads;
     const int* hdr = reinterpret_cast<const int*>(S->model_blob);
     L.nodes = Mv->nodes;
     L.d = (LDS_AS double*)((LDS_AS unsigned char*)smem + hdr[SMPLX_BH_BYTES]);
@@ -612,7 +615,7 @@ __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__
     L.slot_base = 3 * Mv->nroot;
     L.q_base = 3 * Mv->nroot + 12 * Mv->nslots;
     const int nd = 3 * Mv->nroot + 12 * Mv->nslots + Mv->nvars;
-    L.stk = (LDS_AS unsigned char*)(L.d + nd * BLOCK);
+    L.stk = (LDS_AS unsigned char*)(L.d + nd * nthreads);
     __syncthreads();
     return L;
 }
@@ -707,9 +710,18 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
         const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // second pass after the pipeline (deferred_count != nullptr): nothing to do in the common case
+    // second pass after the pipeline / the small-batch kernel (deferred_count != nullptr): nothing to do in the
+    // common case.  deferred_count[0] < 0 means "no counter kept": the block looks at its own flags instead.
     const bool only_deferred = deferred_count != nullptr;
-    if (only_deferred && deferred_count[0] == 0) return;
+    if (only_deferred) {
+        const int cnt = deferred_count[0];
+        if (cnt == 0) return;
+        if (cnt < 0) {
+            const long long tid0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+            const int mine = (tid0 < (long long)B * S->actions.nprims) ? (out_flags[tid0] & SMPLX_F_DEFERRED) : 0;
+            if (!__syncthreads_or(mine)) return;
+        }
+    }
     ModelLds Mv;
     const SmplxActionsDev& A = S->actions;
     ThreadLds L = setup_lds(S, smem, &Mv);
@@ -1086,6 +1098,194 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         const unsigned long long m_eval = __ballot(evaluated);
         const unsigned long long m_valid = __ballot((flags & SMPLX_F_VALID) != 0);
         tally_block(counters, __popcll(m_eval), __popcll(m_valid), lookups, performed, ncfg, slk);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small frontier batches (a search that misses on a handful of states): ONE launch instead of the four-kernel
+// pipeline, because at this size the cost is launch + dependency latency, not throughput.
+// One block per state, 8 lanes per primitive:
+//   lanes 0..6 of an edge  -> waypoints 1..7 of its collision check (configuration each)
+//   lane  7   of an edge   -> the successor's own bookkeeping: planning-link FK, heuristic, coordinates, goal test
+//   2 extra threads        -> the state itself (waypoint 0 of every edge) and its planning-link FK (goal distance)
+// Nothing waits for the gating: every primitive is evaluated and the goal-distance gate is applied when the lanes
+// of an edge combine (ballot over its 8 lanes), so all FK chains run concurrently.  Results are identical to the
+// pipeline.  Edges with more than 8 waypoints are deferred to k_expand like pipeline overflow.
+// ---------------------------------------------------------------------------------------------
+#define SMPLX_SMALL_LANES 8
+
+extern "C" __global__ void __launch_bounds__(512)
+k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+              double* __restrict__ goal_dist_out, unsigned char* __restrict__ state_bad_out, int* __restrict__ state_lookups_out,
+              unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
+              int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups, int* __restrict__ deferred_count,
+              const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
+              unsigned char* __restrict__ host_flags, int* __restrict__ host_coord, double* __restrict__ host_q,
+              int* __restrict__ host_h)
+{
+    // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
+    // as a few KB of PCIe stores than as four DMA copies); Q may itself be pinned host memory -- the parent's
+    // joint values are staged into LDS once per block
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_goal_dist;
+    __shared__ int s_state_bad, s_state_lookups;
+    __shared__ double s_parent[SMPLX_MAX_VARS];
+    const int nth = blockDim.x;
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv, nth);
+    const ModelLds* M = &Mv;
+    const SmplxActionsDev& A = S->actions;
+    const SmplxGridDev grid = S->grid;
+    const int si = blockIdx.x;
+    const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
+    const SmplxBfsDev bfs = Sq->bfs;
+    const int nprims = A.nprims, nv = M->nvars;
+    const int t = threadIdx.x;
+    const int pi = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
+    const bool edge_thread = pi < nprims;
+    if (t < nv) s_parent[t] = Q[(refs ? refs[si] : (int64_t)si) * nv + t];
+    __syncthreads();
+    const double* parent = s_parent;
+    const long long eid = (long long)si * nprims + pi;
+
+    // ---- the two state-level roles ----
+    if (t == nprims * SMPLX_SMALL_LANES) {            // the state itself: waypoint 0 of each edge
+        EdgeRef e;
+        e.start = parent; e.finish = parent; e.alpha = 0.0;
+        int lk = 0;
+        const bool ok = config_valid(M, L, grid, e, lk);
+        s_state_bad = ok ? 0 : 1;
+        s_state_lookups = lk;
+        state_bad_out[si] = ok ? 0 : 1;
+        state_lookups_out[si] = lk;
+    } else if (t == nprims * SMPLX_SMALL_LANES + 1) {  // metric goal distance of the state (bfs_heuristic.cpp:129-138)
+        double p[3];
+        planning_fk(M, parent, p);
+        int c[3];
+        world_to_cell(grid, p, c);
+        const double gd = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
+        s_goal_dist = gd;
+        goal_dist_out[si] = gd;
+    }
+
+    // ---- per edge: successor joint values (lane 0 writes them), limits, waypoint count ----
+    int type = 0, W = 0;
+    bool have_action = false, limits_ok = false;
+    double* sq = out_q + eid * nv;
+    if (edge_thread) {
+        type = A.type[pi];
+        if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) have_action = true;
+        else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) have_action = true;
+        if (have_action && slot == 0) {
+            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+                double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
+                if (A.xy_rotate_by_var3 && nv > 3) {
+                    double s, c;
+                    smplx_sincos(parent[3], &s, &c);
+                    const double a0 = d0, a1 = d1;
+                    d0 = c * a0 + (-s) * a1;
+                    d1 = s * a0 + c * a1;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
+                    sq[v] = d + parent[v];
+                }
+            } else {
+                for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];
+            }
+        }
+    }
+    __syncthreads();   // successor joint values are in memory for every lane of their edge
+    if (edge_thread && have_action) {
+        limits_ok = check_joint_limits(M, sq);
+        if (limits_ok) {
+            double motion = 0.0;
+            for (int v = 0; v < nv; ++v) {
+                const int ty = M->var_type[v];
+                const double sv = parent[v], fv = sq[v];
+                if (ty == SMPLX_JT_CONTINUOUS) motion += M->var_k[v] * fabs(smplx_shortest_angle_diff(fv, sv));
+                else if (ty == SMPLX_JT_REVOLUTE) motion += M->var_k[v] * fabs(fv - sv);
+                else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
+            }
+            if (motion != 0.0) {
+                W = (int)ceil(motion / 0.05) + 1;
+                if (W < 2) W = 2;
+            }
+        }
+    }
+    const bool too_long = W - 1 > SMPLX_SMALL_LANES - 1;
+
+    // ---- lanes 0..6: one waypoint each; lane 7: the successor's bookkeeping ----
+    int my_bad = 0, my_lk = 0;
+    int h = 0, is_goal = 0;
+    if (edge_thread && have_action && limits_ok && !too_long) {
+        if (slot < SMPLX_SMALL_LANES - 1) {
+            if (slot < W - 1) {
+                EdgeRef e;
+                e.start = parent; e.finish = sq;
+                e.alpha = (double)(slot + 1) * (1.0 / (double)(W - 1));
+                const bool ok = config_valid(M, L, grid, e, my_lk);
+                my_bad = ok ? 0 : 1;
+            }
+        } else {
+            int* sc = out_coord + eid * nv;
+            for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
+            double p[3];
+            planning_fk(M, sq, p);
+            if (Sq->goal.type == SMPLX_GOAL_JOINT) {
+                is_goal = 1;
+                for (int v = 0; v < nv; ++v)
+                    if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = 0;
+            } else {
+                is_goal = fabs(p[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(p[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
+                          fabs(p[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
+            }
+            int c[3];
+            world_to_cell(grid, p, c);
+            h = bfs_cost_to_goal(bfs, c);
+        }
+    }
+    __syncthreads();   // the state's own check and the goal distance have landed in LDS
+
+    // ---- combine the 8 lanes of each edge (they sit in one wave) ----
+    const unsigned long long bad_mask = __ballot(my_bad);
+    int lk = my_lk;
+    lk += __shfl_xor(lk, 1); lk += __shfl_xor(lk, 2); lk += __shfl_xor(lk, 4);
+    if (edge_thread && slot == SMPLX_SMALL_LANES - 1) {
+        const int lane = t & 63;
+        const bool edge_bad = ((bad_mask >> (lane & ~7)) & 0xFFull) != 0;
+        int flags;
+        int lookups = 0, cost = 0, hh = 0;
+        if (!have_action || !mprim_active(A, s_goal_dist, type)) {
+            flags = SMPLX_F_INACTIVE;
+        } else if (!limits_ok) {
+            flags = SMPLX_F_LIMITS;
+        } else if (too_long) {
+            flags = SMPLX_F_DEFERRED;
+            if (deferred_count) atomicAdd(deferred_count, 1);
+        } else {
+            lookups = lk + (W > 0 ? s_state_lookups : 0);
+            const bool ok = (W == 0) || (s_state_bad == 0 && !edge_bad);
+            if (!ok) {
+                flags = SMPLX_F_COLLISION;
+            } else {
+                flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
+                hh = h;
+                cost = A.cost[pi];
+            }
+        }
+        out_flags[eid] = (unsigned char)flags;
+        out_h[eid] = hh;
+        out_cost[eid] = cost;
+        out_lookups[eid] = lookups;
+        if (host_flags) {
+            host_flags[eid] = (unsigned char)flags;
+            if (flags & SMPLX_F_VALID) {
+                host_h[eid] = hh;
+                const int* sc = out_coord + eid * nv;
+                for (int v = 0; v < nv; ++v) { host_coord[eid * nv + v] = sc[v]; host_q[eid * nv + v] = sq[v]; }
+            }
+        }
     }
 }
 

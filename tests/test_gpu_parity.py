@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEG = scenes.DEG
 
 
-@pytest.fixture(scope="module", params=["pipeline", "fused"])
+@pytest.fixture(scope="module", params=["pipeline", "fused", "small"])
 def ctx(small_cfg, request):
     from oracle_binding import Oracle
     from smpl_amd import capi
@@ -23,7 +23,9 @@ def ctx(small_cfg, request):
         pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
     o = Oracle(small_cfg)
     o.set_order(chain=True)   # the kernel walks the sphere trees link by link (same booleans, see oracle)
-    s = capi.Space.from_config(small_cfg, fused=(request.param == "fused"))
+    # "pipeline": four-kernel waypoint-parallel path forced for every batch size; "small": batches <= 256 states take
+    # the single-launch kernel (the default policy); "fused": one thread per edge
+    s = capi.Space.from_config(small_cfg, fused=(request.param == "fused"), no_small_kernel=(request.param == "pipeline"))
     s.fused = request.param == "fused"
     o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
     s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
@@ -172,14 +174,14 @@ def test_getsuccs_ids_match_sequential_reference_order(ctx):
         assert o.heuristic_q(eq) == s.goal_heuristic(i)
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "pipeline-only"])
 @pytest.mark.parametrize("goal_kind", ["joint", "xyz"])
 def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused):
     from oracle_binding import Oracle
     from smpl_amd import capi
     cfg = small_cfg
     o = Oracle(cfg)
-    s = capi.Space.from_config(cfg, batch_states=256, fused=fused)
+    s = capi.Space.from_config(cfg, batch_states=256, fused=(fused is True), no_small_kernel=(fused == "pipeline-only"))
     if goal_kind == "joint":
         o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
     else:
