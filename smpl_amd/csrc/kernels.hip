@@ -147,27 +147,9 @@ __device__ __forceinline__ void mul_affine(double T[12], const double J[12])
     for (int i = 0; i < 12; ++i) T[i] = R[i];
 }
 
-// One step of the kinematic chain: T = T * J(q), or T = J(q) for a joint on the root link.
-// For origins whose rotation is exactly the identity (SMPLX_TK_*_T) the general form
-//   J = origin * R_axis(q)   (transform_functions.h:104-207),   T' = T * J   (robot_collision_state.h:419-421)
-// multiplies by 0 and 1 only; the terms x*1 and y*0 are exact, adding +-0 changes no non-zero value, and
-// a*(-s) + b*c == b*c - a*s bit for bit, so the shortened expressions below give identical bits.
-__device__ __forceinline__ void apply_joint(JointPtr jt, double q, double T[12], bool on_root)
+// the identity-origin forms (SMPLX_TK_*_T) with the origin's translation already in registers
+__device__ __forceinline__ void apply_joint_t(int kind, double tx, double ty, double tz, double q, double T[12], bool on_root)
 {
-    const int kind = jt->kind;
-    if (kind < SMPLX_TK_FIXED_T) {
-        double J[12];
-        joint_matrix(jt, q, J);
-        if (on_root) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = J[i];
-        } else {
-            mul_affine(T, J);
-        }
-        return;
-    }
-    DblPtr o = jt->origin;
-    const double tx = o[3], ty = o[7], tz = o[11];
     if (on_root) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = 0.0;
@@ -196,6 +178,29 @@ __device__ __forceinline__ void apply_joint(JointPtr jt, double q, double T[12],
         else if (kind == SMPLX_TK_REV_Y_T) { T[4 * i + 0] = a * c - d * s; T[4 * i + 2] = a * s + d * c; }
         else { T[4 * i + 0] = a * c + b * s; T[4 * i + 1] = b * c - a * s; }
     }
+}
+
+// One step of the kinematic chain: T = T * J(q), or T = J(q) for a joint on the root link.
+// For origins whose rotation is exactly the identity (SMPLX_TK_*_T) the general form
+//   J = origin * R_axis(q)   (transform_functions.h:104-207),   T' = T * J   (robot_collision_state.h:419-421)
+// multiplies by 0 and 1 only; the terms x*1 and y*0 are exact, adding +-0 changes no non-zero value, and
+// a*(-s) + b*c == b*c - a*s bit for bit, so the shortened expressions below give identical bits.
+__device__ __forceinline__ void apply_joint(JointPtr jt, double q, double T[12], bool on_root)
+{
+    const int kind = jt->kind;
+    if (kind < SMPLX_TK_FIXED_T) {
+        double J[12];
+        joint_matrix(jt, q, J);
+        if (on_root) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = J[i];
+        } else {
+            mul_affine(T, J);
+        }
+        return;
+    }
+    DblPtr o = jt->origin;
+    apply_joint_t(kind, o[3], o[7], o[11], q, T, on_root);
 }
 
 // voxel lookup: squared cell distance at a world point, 0 outside the grid
@@ -347,6 +352,22 @@ __device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, 
     return true;
 }
 
+// the part of a joint record the chain step needs, in registers
+struct JointHead {
+    int kind, var, src, save_slot, tree;
+    double tx, ty, tz, q;
+};
+
+__device__ __forceinline__ JointHead load_joint_head(const ModelLds* __restrict__ M, const ThreadLds& L, int j)
+{
+    JointPtr jt = &M->joints[j];
+    JointHead h;
+    h.kind = jt->kind; h.var = jt->var; h.src = jt->src; h.save_slot = jt->save_slot; h.tree = jt->tree;
+    h.tx = jt->origin[3]; h.ty = jt->origin[7]; h.tz = jt->origin[11];
+    h.q = h.var >= 0 ? lds_d(L, L.q_base + h.var) : 0.0;
+    return h;
+}
+
 // CollisionSpace::isStateValid for one configuration (collision_space.cpp:532-536 ->
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
@@ -361,20 +382,26 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
     int npending = 0;
     stage_config(M, L, e);
     const int nj = M->njoints;
+    JointHead cur = load_joint_head(M, L, 0);
     for (int j = 0; j < nj; ++j) {
-        JointPtr jt = &M->joints[j];
-        const double q = jt->var >= 0 ? config_var(M, L, jt->var) : 0.0;
-        if (jt->src >= 0) {
+        // the next joint's record is requested from LDS now and consumed an iteration later, so its latency hides
+        // behind this joint's sincos and products
+        JointHead nxt = cur;
+        if (j + 1 < nj) nxt = load_joint_head(M, L, j + 1);
+        if (cur.src >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * jt->src + i);
+            for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * cur.src + i);
         }
-        apply_joint(jt, q, T, jt->src == SMPLX_SRC_ROOT);
-        if (jt->save_slot >= 0) {
+        if (cur.kind >= SMPLX_TK_FIXED_T) apply_joint_t(cur.kind, cur.tx, cur.ty, cur.tz, cur.q, T, cur.src == SMPLX_SRC_ROOT);
+        else apply_joint(&M->joints[j], cur.q, T, cur.src == SMPLX_SRC_ROOT);
+        if (cur.save_slot >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * jt->save_slot + i) = T[i];
+            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * cur.save_slot + i) = T[i];
         }
-        if (jt->tree >= 0) {
-            const int t = jt->tree;
+        const int jtree = cur.tree;
+        cur = nxt;
+        if (jtree >= 0) {
+            const int t = jtree;
             double rp[3];
             if (!check_tree(M, L, g, t, T, lookups, rp)) return false;   // voxel collision: the reference stops here too
             const int slot = M->tree_root_slot[t];
