@@ -37,6 +37,9 @@ SMPLX_HD void smplx_sincos(double x, double* s_out, double* c_out)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+#ifdef ABL_NO_SINCOS
+    *s_out = x * 0.5; *c_out = 1.0 - x * 0.25; return;
+#endif
     const double fn = rint(x * INVPIO2);
     const int n = (int)fn;
     const double r = ((x - fn * P1) - fn * P2) - fn * P3;

@@ -237,7 +237,11 @@ __device__ __forceinline__ bool check_tree(const ModelLds* __restrict__ M, const
         xform(T, c, p);
         if (node == root) { root_p[0] = p[0]; root_p[1] = p[1]; root_p[2] = p[2]; }
         ++lookups;
+#ifdef ABL_NO_LOOKUP
+        const int d2 = 60000 + (int)(p[0] * 0.0);
+#else
         const int d2 = grid_d2(g, p);
+#endif
         if (d2 < nd.thr) {              // CheckSphereCollision fails (collision_operations.h:67-77)
             if (nd.left < 0) return false;
             const double rl = L.nodes[nd.left].r, rr = L.nodes[nd.right].r;
@@ -380,6 +384,9 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
     bool pair_hit = false, recheck_all = false;
     unsigned long long pending = 0;   // queued (earlier tree, later tree) pairs, 16 bits each
     int npending = 0;
+#ifdef ABL_NO_FK
+    lookups += (int)e.alpha; return true;
+#endif
     stage_config(M, L, e);
     const int nj = M->njoints;
     JointHead cur = load_joint_head(M, L, 0);
@@ -403,7 +410,11 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
         if (jtree >= 0) {
             const int t = jtree;
             double rp[3];
+#ifdef ABL_NO_TREES
+            rp[0] = T[3]; rp[1] = T[7]; rp[2] = T[11];
+#else
             if (!check_tree(M, L, g, t, T, lookups, rp)) return false;   // voxel collision: the reference stops here too
+#endif
             const int slot = M->tree_root_slot[t];
             if (slot >= 0) {
                 lds_d(L, L.root_base + 3 * slot + 0) = rp[0];
@@ -415,7 +426,11 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
             // transform slots).  A hit does not stop the voxel pass: the reference runs ALL voxel checks before
             // the first pair (self_collision_model.cpp:418-421), so lookup tallies stay identical.
             const LDS_AS SmplxNode& B = L.nodes[M->tree_first[t + 1] - 1];
+#ifdef ABL_NO_PAIRS
+            for (int k = 0; k < 0; ++k) {
+#else
             for (int k = M->pair_first[t]; k < M->pair_first[t + 1]; ++k) {
+#endif
                 const int ta = M->pair_other[k];
                 const int sa = M->tree_root_slot[ta];
                 const LDS_AS SmplxNode& A = L.nodes[M->tree_first[ta + 1] - 1];
