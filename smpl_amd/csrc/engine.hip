@@ -150,6 +150,7 @@ struct smplx_space {
     SmplxSpaceDev hs;
     SmplxSpaceDev* d_space = nullptr;
     hipStream_t stream = nullptr;
+    int device = 0;   // HIP device the handle lives on (worker threads select it explicitly)
     int N = 0, M = 0;
     size_t lds_bytes = 0, blob_bytes = 0;
     // BFS
@@ -785,6 +786,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
         return set_error(SMPLX_E_HIP, msg);
     };
     hipError_t e;
+    if ((e = hipGetDevice(&s->device)) != hipSuccess) return bail(e, "hipGetDevice");
     if ((e = hipStreamCreate(&s->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipEventCreateWithFlags(&s->batch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
@@ -1404,6 +1406,7 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
               std::chrono::steady_clock::time_point t0)
 {
     smplx_space* lead = spaces[q0];
+    HIP_TRY(hipSetDevice(lead->device));   // a fresh host thread starts on device 0
     const int nq = q1 - q0;
     int remaining = nq;
         const int N = lead->N, M = lead->M;
