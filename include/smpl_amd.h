@@ -199,6 +199,21 @@ int smplx_expansion_log(const smplx_space* s, int32_t* out);
 /* ManipLattice::extractPath for a plain id path (manip_lattice.cpp:2018-2155): q[len][nvars] */
 int smplx_extract_path(smplx_space* s, const int32_t* ids, int len, double* q);
 
+/* --- path post-processing: PlannerInterface::postProcessPath (smpl_ros/src/ros/planner_interface.cpp:2651-2697) over
+ * ShortcutPath(JOINT_SPACE) (smpl/src/post_processing.cpp:281-309, smpl/include/smpl/geometry/detail/shortcut.hpp:110-286)
+ * and InterpolatePath (post_processing.cpp:464-523).  path: n points of nvars doubles.  The collision questions of the
+ * greedy loops are answered from waypoint-parallel GPU batches.  stats (may be NULL): [0] edge batches, [1] configurations
+ * checked.  out may be NULL to query the size. */
+enum {
+    SMPLX_PP_SHORTCUT = 1,          /* shortcut_path */
+    SMPLX_PP_INTERPOLATE = 2,       /* interpolate_path */
+    SMPLX_PP_UPSTREAM_LIMITS = 4    /* use upstream's limit test in CollisionSpace::interpolatePath; the default is the
+                                       fork's (collision_space.cpp:592-597), under which interpolation of an in-limits
+                                       path reports failure and leaves the path as it was */
+};
+int smplx_post_process_path(smplx_space* s, const double* path, int n, int flags, double* out, int cap, int* nout,
+                            int64_t* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,4 +216,25 @@ private:
     GpuPlanningContext* ctx_;
 };
 
+// sbpl::motion::PlannerInterface::postProcessPath (smpl_ros/src/ros/planner_interface.cpp:2651-2697): ShortcutPath with
+// ShortcutType::JOINT_SPACE (smpl/include/smpl/post_processing.h:49-71) between two InterpolatePath passes.  The greedy
+// loops are the reference's; their collision questions are answered from waypoint-parallel GPU batches.
+// upstream_limit_test = false keeps the fork's CollisionSpace::interpolatePath limit test (collision_space.cpp:592-597).
+inline bool PostProcessPath(GpuPlanningContext* ctx, std::vector<RobotState>& path, bool shortcut_path, bool interpolate_path,
+                            bool upstream_limit_test = false)
+{
+    const int N = ctx->nvars();
+    std::vector<double> in(path.size() * (size_t)N);
+    for (size_t i = 0; i < path.size(); ++i) std::copy(path[i].begin(), path[i].end(), in.begin() + i * N);
+    const int flags = (shortcut_path ? SMPLX_PP_SHORTCUT : 0) | (interpolate_path ? SMPLX_PP_INTERPOLATE : 0) |
+                      (upstream_limit_test ? SMPLX_PP_UPSTREAM_LIMITS : 0);
+    int n = 0;
+    if (smplx_post_process_path(ctx->space(), in.data(), (int)path.size(), flags, nullptr, 0, &n, nullptr) != SMPLX_OK) return false;
+    std::vector<double> out((size_t)std::max(n, 1) * N);
+    if (smplx_post_process_path(ctx->space(), in.data(), (int)path.size(), flags, out.data(), n, &n, nullptr) != SMPLX_OK) return false;
+    path.clear();
+    for (int i = 0; i < n; ++i) path.emplace_back(out.begin() + (size_t)i * N, out.begin() + (size_t)(i + 1) * N);
+    return true;
+}
+
 }  // namespace smpl_amd

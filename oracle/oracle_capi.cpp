@@ -393,6 +393,22 @@ void orc_expansion_log(void* h, int* out)
 }
 long orc_total_lookups(void* h) { return ((Ctx*)h)->grid.lookups; }
 
+// --- path post-processing (N3).  mode bits: 1 shortcut, 2 interpolate, 4 upstream limit test (fork bug off)
+int orc_post_process(void* h, const double* path, int n, int mode, double* out, int cap, long* edge_checks, long* state_checks)
+{
+    Ctx* c = (Ctx*)h;
+    const int N = c->robot.jointVariableCount();
+    std::vector<std::vector<double>> p(n);
+    for (int i = 0; i < n; ++i) p[i].assign(path + (size_t)i * N, path + (size_t)(i + 1) * N);
+    PostProcessor pp{&c->robot, c->cc.get()};
+    pp.fork_interpolate_limits_bug = !(mode & 4);
+    pp.postProcessPath(p, (mode & 1) != 0, (mode & 2) != 0);
+    for (int i = 0; i < (int)p.size() && i < cap; ++i) std::copy(p[i].begin(), p[i].end(), out + (size_t)i * N);
+    if (edge_checks) *edge_checks = pp.edge_checks;
+    if (state_checks) *state_checks = pp.state_checks;
+    return (int)p.size();
+}
+
 // --- intrusive heap exerciser: ops[i] = {code, key}; codes 0 push(new elem with key), 1 pop,
 // 2 decrease(elem index key>>20 to priority key&0xFFFFF), 3 erase(elem index key), 4 make (after
 // rewriting all priorities p -> (p*7919+13)%1000), 5 increase(elem, priority).  Emits the element

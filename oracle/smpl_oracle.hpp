@@ -1638,6 +1638,145 @@ struct ManipLattice {
 };
 
 // ---------------------------------------------------------------------------
+// path post-processing: smpl/src/post_processing.cpp:52-67 (distance), 100-127 (joint-space
+// shortcut generator), 281-309 (ShortcutPath, JOINT_SPACE), 430-445 (costs), 464-523 (InterpolatePath);
+// the generic loop of smpl/include/smpl/geometry/detail/shortcut.hpp:110-286 with one generator and
+// granularity 1 (shortcut.h:98-99 defaults, comparator std::less_equal); PlannerInterface::postProcessPath
+// smpl_ros/src/ros/planner_interface.cpp:2651-2697.
+// ---------------------------------------------------------------------------
+
+struct PostProcessor {
+    PlanningRobotModel* robot;
+    CollisionSpace* cc;
+    bool fork_interpolate_limits_bug = true;   // [FORK] collision_space.cpp:592-597 rejects paths that ARE within limits
+    long edge_checks = 0, state_checks = 0;
+
+    // post_processing.cpp:52-67
+    double distance(const std::vector<double>& from, const std::vector<double>& to) const
+    {
+        double dist = 0.0;
+        for (size_t v = 0; v < from.size(); ++v) {
+            if (!robot->bounded[v]) dist += shortest_angle_dist(to[v], from[v]);
+            else dist += std::fabs(to[v] - from[v]);
+        }
+        return dist;
+    }
+    // JointPositionShortcutPathGenerator (:100-127)
+    bool generate(const std::vector<double>& a, const std::vector<double>& b, double& cost)
+    {
+        ++edge_checks;
+        if (!cc->isStateToStateValid(a, b)) return false;
+        cost = distance(a, b);
+        return true;
+    }
+    // shortcut.hpp:110-286
+    void shortcutPath(const std::vector<std::vector<double>>& pin, std::vector<std::vector<double>>& pout)
+    {
+        pout.clear();
+        const size_t psize = pin.size();
+        if (psize < 2) { pout = pin; return; }
+        std::vector<double> accum(psize);
+        accum[0] = 0.0;
+        for (size_t i = 1; i < psize; ++i) accum[i] = accum[i - 1] + distance(pin[i - 1], pin[i]);
+        const size_t granularity = 1;
+        size_t start = 0, end = std::min(psize - 1, granularity);
+        // the best path of the segment of interest: either the original points [start, end] or a direct connection
+        bool best_direct = false;
+        size_t best_last = end;            // last original index the best path reaches
+        double best_cost = accum[end] - accum[start];
+        double cost = 0.0;
+        if (generate(pin[start], pin[end], cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
+        pout.push_back(pin[0]);
+        auto emit_best = [&]() {
+            if (best_direct) pout.push_back(pin[best_last]);
+            else for (size_t i = start + 1; i <= best_last; ++i) pout.push_back(pin[i]);
+        };
+        while (end != psize) {
+            bool improved = false;
+            const size_t look_dist = std::min(granularity, psize - end - 1);   // distance(curr_end, plast) - 1
+            if (look_dist != 0) {
+                const double exp_cost = accum[end + look_dist] - accum[end];
+                double new_cost = best_cost + exp_cost;
+                if (generate(pin[start], pin[end + look_dist], cost) && cost <= new_cost) {
+                    improved = true;
+                    best_direct = true;
+                    best_last = end + look_dist;
+                    new_cost = cost;
+                }
+                best_cost = new_cost;
+            }
+            if (improved) {
+                end += look_dist;
+            } else if (look_dist == 0) {
+                end = psize;
+            } else {
+                emit_best();
+                start = end;
+                end += look_dist;
+                best_direct = false;
+                best_last = end;
+                best_cost = accum[end] - accum[start];
+                if (generate(pin[start], pin[end], cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
+            }
+        }
+        emit_best();
+    }
+    // collision_space.cpp:583-612 + 776-793
+    bool withinLimits(const std::vector<double>& q) const
+    {
+        for (size_t v = 0; v < q.size(); ++v) {
+            if (!(robot->continuous[v] || !robot->bounded[v] || (q[v] >= robot->min_limits[v] && q[v] <= robot->max_limits[v]))) return false;
+        }
+        return true;
+    }
+    bool ccInterpolate(const std::vector<double>& a, const std::vector<double>& b, std::vector<std::vector<double>>& out) const
+    {
+        const bool wa = withinLimits(a), wb = withinLimits(b);
+        if (fork_interpolate_limits_bug ? (wa || wb) : (!wa || !wb)) return false;
+        const int W = cc->waypointCount(a, b);
+        std::vector<double> diffs;
+        cc->interpolationDiffs(a, b, diffs);
+        const double inv = W > 0 ? 1.0 / (double)(W - 1) : 0.0;
+        out.assign(W, std::vector<double>(a.size()));
+        for (int n = 0; n < W; ++n) {
+            const double alpha = (double)n * inv;
+            for (size_t v = 0; v < a.size(); ++v) out[n][v] = a[v] + alpha * diffs[v];
+        }
+        return true;
+    }
+    // post_processing.cpp:464-523
+    bool interpolatePath(std::vector<std::vector<double>>& path)
+    {
+        if (path.empty()) return true;
+        std::vector<std::vector<double>> opath;
+        opath.push_back(path.front());
+        for (size_t i = 0; i + 1 < path.size(); ++i) {
+            std::vector<std::vector<double>> ipath;
+            if (!ccInterpolate(path[i], path[i + 1], ipath)) return false;
+            bool collision = false;
+            for (const auto& pt : ipath) {
+                ++state_checks;
+                if (!cc->isStateValid(pt)) { collision = true; break; }
+            }
+            if (collision) { opath.push_back(path[i + 1]); continue; }
+            if (!ipath.empty()) opath.insert(opath.end(), ipath.begin() + 1, ipath.end());
+        }
+        path = std::move(opath);
+        return true;
+    }
+    // planner_interface.cpp:2651-2697 (shortcut_path and interpolate_path both requested)
+    void postProcessPath(std::vector<std::vector<double>>& path, bool shortcut, bool interpolate)
+    {
+        if (shortcut) {
+            (void)interpolatePath(path);   // on failure the path is left as it was (:2661-2666)
+            std::vector<std::vector<double>> ipath = path;
+            shortcutPath(ipath, path);
+        }
+        if (interpolate) (void)interpolatePath(path);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // intrusive_heap (smpl/include/smpl/detail/intrusive_heap.hpp:145-166, 346-395)
 // Index 0 is unused; element positions are kept in the elements themselves.
 // PINNED by oracle/_ref/heap_ref (the reference header compiled in place).

@@ -28,7 +28,7 @@ SYMBOLS = [
     "smplx_heuristic_batch", "smplx_bfs_size", "smplx_bfs_copy", "smplx_bfs_levels", "smplx_expand_batch",
     "smplx_expand_work_bytes", "smplx_expand_batch_device", "smplx_set_start", "smplx_start_id", "smplx_goal_id",
     "smplx_get_succs", "smplx_hint_frontier", "smplx_get_goal_heuristic", "smplx_num_states", "smplx_get_state",
-    "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_profile_begin",
+    "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_post_process_path", "smplx_profile_begin",
     "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read", "smplx_plan_multi",
 ]
 
@@ -363,6 +363,17 @@ class Space:
             d["expansion_log"] = log
             out.append(d)
         return out, wall.value
+
+    def post_process_path(self, path, shortcut=True, interpolate=True, upstream_limits=False):
+        """PlannerInterface::postProcessPath (planner_interface.cpp:2651-2697).  Returns (path, stats)."""
+        path = np.ascontiguousarray(path, np.float64).reshape(-1, self.N)
+        flags = (1 if shortcut else 0) | (2 if interpolate else 0) | (4 if upstream_limits else 0)
+        n = C.c_int(); st = (C.c_int64 * 2)()
+        lib().smplx_post_process_path.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, _ip, C.POINTER(C.c_int64)]
+        _chk(lib().smplx_post_process_path(self.h, _p(path, _dp), path.shape[0], flags, None, 0, C.byref(n), st))
+        out = np.zeros((max(n.value, 1), self.N))
+        _chk(lib().smplx_post_process_path(self.h, _p(path, _dp), path.shape[0], flags, _p(out, _dp), out.shape[0], C.byref(n), st))
+        return out[:n.value], dict(edge_batches=st[0], configs=st[1])
 
     def extract_path(self, ids):
         ids = np.ascontiguousarray(ids, np.int32); q = np.zeros((ids.shape[0], self.N))

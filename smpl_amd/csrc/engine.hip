@@ -1653,4 +1653,233 @@ int smplx_extract_path(smplx_space* s, const int32_t* ids, int len, double* q)
     return SMPLX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// path post-processing.  The greedy loops are the reference's, run on the host; what they ask of
+// the collision checker -- isStateToStateValid for the shortcut generator, isStateValid for every interpolated
+// point -- is answered from waypoint-parallel GPU batches (k_state_valid over all waypoints of all candidate
+// edges of the current segment start), so the answers are those of the sequential checker (an edge is valid iff
+// all its waypoints are, collision_space.cpp:538-581).
+// ---------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct PathTools {
+    smplx_space* s;
+    int N;
+    const SmplxModelDev& M;
+    long edge_batches = 0, configs = 0;
+    explicit PathTools(smplx_space* sp) : s(sp), N(sp->N), M(sp->model.dev) {}
+
+    int waypoint_count(const double* a, const double* b) const
+    {
+        int W = 0;
+        (void)smplx_cc_interpolate(s, a, b, nullptr, 0, &W);
+        return W;
+    }
+    void append_waypoints(const double* a, const double* b, int W, std::vector<double>& out) const
+    {
+        const size_t o = out.size();
+        out.resize(o + (size_t)W * N);
+        int n = 0;
+        (void)smplx_cc_interpolate(s, a, b, out.data() + o, W, &n);
+    }
+    // post_processing.cpp:52-67
+    double distance(const double* from, const double* to) const
+    {
+        double dist = 0.0;
+        for (int v = 0; v < N; ++v) {
+            if (M.var_type[v] == SMPLX_JT_CONTINUOUS) dist += std::fabs(smplx_shortest_angle_diff(to[v], from[v]));
+            else dist += std::fabs(to[v] - from[v]);
+        }
+        return dist;
+    }
+    // collision_space.cpp:776-793
+    bool within_limits(const double* q) const
+    {
+        for (int v = 0; v < N; ++v) {
+            if (M.var_type[v] == SMPLX_JT_CONTINUOUS) continue;
+            if (!(q[v] >= M.var_min[v] && q[v] <= M.var_max[v])) return false;
+        }
+        return true;
+    }
+    int states_valid(const std::vector<double>& q, std::vector<uint8_t>& valid)
+    {
+        const int n = (int)(q.size() / N);
+        valid.assign(n, 0);
+        configs += n;
+        return smplx_cc_state_valid_batch(s, q.data(), n, valid.data(), nullptr);
+    }
+};
+
+// validity of the edges (start, j), j > start, filled lazily in waypoint-budgeted batches
+struct EdgeOracle {
+    PathTools& T;
+    const double* path;
+    int P;
+    int start = -1;
+    std::vector<int8_t> known;   // per j: -1 unknown, 0 invalid, 1 valid
+    static constexpr int kBudget = 1 << 16;   // waypoints per batch
+
+    int query(int st, int j, bool& ok)
+    {
+        if (st != start) { start = st; known.assign(P, -1); }
+        if (known[j] < 0) {
+            // speculate: this edge and the following ones from the same start, up to the budget
+            std::vector<double> q;
+            std::vector<int> first;
+            int jj = j, total = 0;
+            for (; jj < P; ++jj) {
+                const int W = T.waypoint_count(path + (size_t)st * T.N, path + (size_t)jj * T.N);
+                if (jj > j && total + W > kBudget) break;
+                first.push_back(total);
+                T.append_waypoints(path + (size_t)st * T.N, path + (size_t)jj * T.N, W, q);
+                total += W;
+            }
+            first.push_back(total);
+            std::vector<uint8_t> valid;
+            if (total > 0) { if (int e = T.states_valid(q, valid)) return e; }
+            ++T.edge_batches;
+            for (int k = 0; k + 1 < (int)first.size(); ++k) {
+                bool all = true;
+                for (int w = first[k]; w < first[k + 1]; ++w) all = all && valid[w] != 0;
+                known[j + k] = all ? 1 : 0;
+            }
+        }
+        ok = known[j] == 1;
+        return SMPLX_OK;
+    }
+};
+
+// shortcut.hpp:110-286 with the joint-space generator (post_processing.cpp:100-127), granularity 1
+int shortcut_path(PathTools& T, const std::vector<double>& pin, std::vector<double>& pout)
+{
+    const int N = T.N;
+    const int P = (int)(pin.size() / N);
+    pout.clear();
+    if (P < 2) { pout = pin; return SMPLX_OK; }
+    auto pt = [&](int i) { return pin.data() + (size_t)i * N; };
+    auto push = [&](int i) { pout.insert(pout.end(), pt(i), pt(i) + N); };
+    std::vector<double> accum(P);
+    accum[0] = 0.0;
+    for (int i = 1; i < P; ++i) accum[i] = accum[i - 1] + T.distance(pt(i - 1), pt(i));
+    EdgeOracle E{T, pin.data(), P};
+    int err = SMPLX_OK;
+    auto generate = [&](int a, int b, double& cost) {
+        bool ok = false;
+        if (int e = E.query(a, b, ok)) { err = e; return false; }
+        if (!ok) return false;
+        cost = T.distance(pt(a), pt(b));
+        return true;
+    };
+    int start = 0, end = 1;
+    bool best_direct = false;
+    int best_last = end;
+    double best_cost = accum[end] - accum[start], cost = 0.0;
+    if (generate(start, end, cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
+    push(0);
+    auto emit_best = [&]() {
+        if (best_direct) push(best_last);
+        else for (int i = start + 1; i <= best_last; ++i) push(i);
+    };
+    while (end != P && err == SMPLX_OK) {
+        bool improved = false;
+        const int look = std::min(1, P - end - 1);
+        if (look != 0) {
+            double new_cost = best_cost + (accum[end + look] - accum[end]);
+            if (generate(start, end + look, cost) && cost <= new_cost) {
+                improved = true;
+                best_direct = true;
+                best_last = end + look;
+                new_cost = cost;
+            }
+            best_cost = new_cost;
+        }
+        if (improved) {
+            end += look;
+        } else if (look == 0) {
+            end = P;
+        } else {
+            emit_best();
+            start = end;
+            end += look;
+            best_direct = false;
+            best_last = end;
+            best_cost = accum[end] - accum[start];
+            if (generate(start, end, cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
+        }
+    }
+    if (err) return err;
+    emit_best();
+    return SMPLX_OK;
+}
+
+// post_processing.cpp:464-523 over CollisionSpace::interpolatePath (collision_space.cpp:583-612); *done = the
+// reference's return value (false leaves the path as it was)
+int interpolate_path(PathTools& T, std::vector<double>& path, bool fork_limits_test, bool* done)
+{
+    const int N = T.N;
+    const int P = (int)(path.size() / N);
+    *done = true;
+    if (P == 0) return SMPLX_OK;
+    std::vector<double> q;
+    std::vector<int> first(1, 0);
+    for (int i = 0; i + 1 < P; ++i) {
+        const double* a = path.data() + (size_t)i * N;
+        const double* b = a + N;
+        const bool wa = T.within_limits(a), wb = T.within_limits(b);
+        // [FORK] :592-597 reports "Joint limits violated" when either end IS within its limits
+        if (fork_limits_test ? (wa || wb) : (!wa || !wb)) { *done = false; return SMPLX_OK; }
+        const int W = T.waypoint_count(a, b);
+        T.append_waypoints(a, b, W, q);
+        first.push_back(first.back() + W);
+    }
+    std::vector<uint8_t> valid;
+    if (!q.empty()) { if (int e = T.states_valid(q, valid)) return e; }
+    std::vector<double> out(path.begin(), path.begin() + N);
+    for (int i = 0; i + 1 < P; ++i) {
+        bool collision = false;
+        for (int w = first[i]; w < first[i + 1]; ++w) collision = collision || valid[w] == 0;
+        if (collision) {
+            out.insert(out.end(), path.begin() + (size_t)(i + 1) * N, path.begin() + (size_t)(i + 2) * N);
+        } else if (first[i + 1] > first[i]) {
+            out.insert(out.end(), q.begin() + (size_t)(first[i] + 1) * N, q.begin() + (size_t)first[i + 1] * N);
+        }
+    }
+    path.swap(out);
+    return SMPLX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smplx_post_process_path(smplx_space* s, const double* path, int n, int flags, double* out, int cap, int* nout,
+                            int64_t* stats)
+{
+    if (!s || (!path && n > 0) || n < 0 || !nout) return set_error(SMPLX_E_ARG, "bad argument");
+    PathTools T(s);
+    std::vector<double> p(path, path + (size_t)n * s->N);
+    const bool fork_test = !(flags & SMPLX_PP_UPSTREAM_LIMITS);
+    bool done = false;
+    // PlannerInterface::postProcessPath (planner_interface.cpp:2651-2697)
+    if (flags & SMPLX_PP_SHORTCUT) {
+        if (int e = interpolate_path(T, p, fork_test, &done)) return e;   // failure leaves the path as it was
+        std::vector<double> in = p;
+        if (int e = shortcut_path(T, in, p)) return e;
+    }
+    if (flags & SMPLX_PP_INTERPOLATE) {
+        if (int e = interpolate_path(T, p, fork_test, &done)) return e;
+    }
+    const int np = (int)(p.size() / s->N);
+    *nout = np;
+    if (stats) { stats[0] = T.edge_batches; stats[1] = T.configs; }
+    if (out) {
+        if (np > cap) return set_error(SMPLX_E_LIMIT, "output path does not fit");
+        std::memcpy(out, p.data(), sizeof(double) * p.size());
+    }
+    return SMPLX_OK;
+}
+
 }  // extern "C"

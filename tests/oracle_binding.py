@@ -231,6 +231,14 @@ class Oracle:
         return dict(ok=ok, path=ids[:n.value].copy(), cost=cost.value, expansions=exp.value, succ_evals=ev.value,
                     eps=eps.value, seconds=sec.value, expansion_log=log)
 
+    def post_process(self, path, shortcut=True, interpolate=True, upstream_limits=False, cap=20000):
+        path = np.ascontiguousarray(path, np.float64).reshape(-1, self.N)
+        out = np.zeros((cap, self.N)); ec, sc = C.c_long(), C.c_long()
+        mode = (1 if shortcut else 0) | (2 if interpolate else 0) | (4 if upstream_limits else 0)
+        self.lib.orc_post_process.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        n = self.lib.orc_post_process(self.h, _p(path, _dp), path.shape[0], mode, _p(out, _dp), cap, C.byref(ec), C.byref(sc))
+        return out[:n].copy(), ec.value, sc.value
+
     def total_lookups(self):
         return self.lib.orc_total_lookups(self.h)
 

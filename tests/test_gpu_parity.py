@@ -205,6 +205,38 @@ def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused):
 
 
 @pytest.fixture(scope="module")
+def planned_path(small_cfg):
+    from smpl_amd import capi
+    cfg = small_cfg
+    s = capi.Space.from_config(cfg, batch_states=256)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_start(cfg.start)
+    go = s.plan(5.0, 1.0, 1.0, True, True, 6000, 3000)
+    assert go["solved"]
+    return s.extract_path(go["path"])
+
+
+@pytest.mark.parametrize("mode", [(True, True, False), (True, True, True), (True, False, True), (False, True, True)])
+def test_post_process_path_equals_reference_loops(ctx, planned_path, mode):
+    """Row N3: shortcut + interpolation of a planned path and of a random zig-zag of valid states: the point
+    sequences are the oracle's, bit for bit."""
+    cfg, o, s = ctx
+    paths = [planned_path]
+    Q = _random_states(400, 77)
+    ok, _ = s.state_valid_batch(Q)
+    paths.append(Q[ok.astype(bool)][:30])
+    paths += [paths[0][:1], paths[0][:2], paths[0][:0]]
+    for P in paths:
+        want, _, _ = o.post_process(P, *mode)
+        got, st = s.post_process_path(P, *mode)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want)
+    # the fork's limit test leaves in-limits paths un-interpolated (collision_space.cpp:592-597)
+    if mode == (False, True, False):
+        assert np.array_equal(got, paths[-1])
+
+
+@pytest.fixture(scope="module")
 def dual_ctx():
     """14-DOF dual arm (SURVEY cfg 5 robot) on a coarse grid: two kinematic chains from the root, 16 sphere trees,
     85 checked link pairs including every inter-arm pair -- exercises the sphere-sphere slow path."""

@@ -231,3 +231,58 @@ def test_libm_sincos_build_gives_the_same_search(small_cfg):
         res.append(x.plan())
     assert res[0]["cost"] == res[1]["cost"]
     assert np.array_equal(res[0]["expansion_log"], res[1]["expansion_log"])
+
+
+# --- path post-processing ---
+
+def _free_line(o, cfg, n, step):
+    P = np.tile(np.array(cfg.start, float), (n, 1))
+    P[:, 0] += step * np.arange(n)
+    assert all(o.state_valid(q)[0] for q in P)
+    return P
+
+
+def test_shortcut_collapses_a_free_straight_line_and_keeps_endpoints(o, small_cfg):
+    # shortcut.hpp:110-286: every extension (start, end+1) is valid and costs exactly the accumulated cost
+    # (dyadic steps: no rounding), "<=" accepts it, so one direct edge remains
+    P = _free_line(o, small_cfg, 9, 1.0 / 64)
+    out, edge_checks, _ = o.post_process(P, shortcut=True, interpolate=False)
+    assert np.array_equal(out, P[[0, -1]])
+    assert edge_checks == len(P) - 1          # (0,1) then (0,2) ... (0,8)
+    for n in (0, 1):
+        out, _, _ = o.post_process(P[:n], shortcut=True, interpolate=False)
+        assert np.array_equal(out, P[:n])
+    out, _, _ = o.post_process(P[:2], shortcut=True, interpolate=False)
+    assert np.array_equal(out, P[:2])
+
+
+def test_shortcut_of_a_planned_path_is_a_valid_subsequence(small_cfg):
+    x = Oracle(small_cfg)
+    x.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    x.set_start(small_cfg.start)
+    x.search_params(5.0, 1.0, 1.0, True, True, 4000, 3000)
+    r = x.plan()
+    assert r["ok"]
+    P = np.array([x.get_state(int(i))[0] if i != 0 else np.array(small_cfg.goal) for i in r["path"]])
+    out, _, _ = x.post_process(P, shortcut=True, interpolate=False)
+    assert 2 <= len(out) < len(P)
+    assert np.array_equal(out[0], P[0]) and np.array_equal(out[-1], P[-1])
+    k = 0
+    for q in out:                              # points of the input, in order
+        while not np.array_equal(P[k], q):
+            k += 1
+    for a, b in zip(out[:-1], out[1:]):
+        assert x.edge_valid(a, b)[0]
+
+
+def test_interpolate_path_fork_limit_test_and_upstream_behaviour(o, small_cfg):
+    P = _free_line(o, small_cfg, 3, 0.25)
+    # [FORK] collision_space.cpp:592-597: an in-limits segment reports "Joint limits violated": the path stays as it was
+    out, _, checks = o.post_process(P, shortcut=False, interpolate=True)
+    assert np.array_equal(out, P) and checks == 0
+    # upstream test: every segment is replaced by its waypoints (post_processing.cpp:464-523), ends kept
+    out, _, checks = o.post_process(P, shortcut=False, interpolate=True, upstream_limits=True)
+    W = [o.waypoint_count(P[i], P[i + 1]) for i in range(2)]
+    assert len(out) == 1 + sum(w - 1 for w in W) and checks == sum(W)
+    assert np.array_equal(out[0], P[0]) and np.array_equal(out[W[0] - 1], P[1]) and np.array_equal(out[-1], P[2])
+    assert np.all(np.diff(out[:, 0]) > 0)
