@@ -253,6 +253,23 @@ def main():
                            "expansions_equal": bool(ro["expansions"] == rg["expansions"]),
                            "expanded_ids_equal": bool(np.array_equal(ro["expansion_log"], rg["expansion_log"])),
                            "path_equal": bool(np.array_equal(ro["path"], rg["path"]))}}
+            if rg["solved"]:
+                # row N3: postProcessPath (interpolate -> shortcut -> interpolate) of the found path, upstream limit
+                # test so that the interpolation passes do their work; GPU entry point vs the oracle's loops
+                P = sp2.extract_path(rg["path"])
+                sp2.post_process_path(P, True, True, True)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    got, st = sp2.post_process_path(P, True, True, True)
+                tg = (time.perf_counter() - t0) / 5
+                t0 = time.perf_counter()
+                want, ec, sc = o2.post_process(P, True, True, True)
+                tc = time.perf_counter() - t0
+                out["planner"]["post_process"] = {
+                    "points_in": int(len(P)), "points_out": int(len(got)), "gpu_ms": round(tg * 1e3, 3),
+                    "cpu_ms": round(tc * 1e3, 3), "gpu_configs_checked": int(st["configs"]),
+                    "gpu_batches": int(st["edge_batches"]), "cpu_edge_checks": int(ec), "cpu_state_checks": int(sc),
+                    "equal": bool(got.shape == want.shape and np.array_equal(got, want))}
 
     if rank == 0 and world == 1 and not args.no_planner and args.multi_queries > 1:
         # batched-query planner leg (BASELINE config 4 shape on one GPU): Q independent queries interleaved by one

@@ -13,6 +13,7 @@
 #include <limits>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/smpl_amd.h"
@@ -1713,63 +1714,62 @@ struct PathTools {
     }
 };
 
-// validity of the edges (start, j), j > start, filled lazily in waypoint-budgeted batches
+// validity of path edges (a, b).  An unknown edge is answered optimistically ("valid") and queued; the caller
+// re-runs its loop after resolve() until a run asks nothing new, so the accepted run saw only checked answers.
 struct EdgeOracle {
     PathTools& T;
     const double* path;
-    int P;
-    int start = -1;
-    std::vector<int8_t> known;   // per j: -1 unknown, 0 invalid, 1 valid
-    static constexpr int kBudget = 1 << 16;   // waypoints per batch
+    std::unordered_map<uint64_t, int8_t> known;
+    std::vector<std::pair<int, int>> pending;
 
-    int query(int st, int j, bool& ok)
+    bool query(int a, int b)
     {
-        if (st != start) { start = st; known.assign(P, -1); }
-        if (known[j] < 0) {
-            // speculate: this edge and the following ones from the same start, up to the budget
-            std::vector<double> q;
-            std::vector<int> first;
-            int jj = j, total = 0;
-            for (; jj < P; ++jj) {
-                const int W = T.waypoint_count(path + (size_t)st * T.N, path + (size_t)jj * T.N);
-                if (jj > j && total + W > kBudget) break;
-                first.push_back(total);
-                T.append_waypoints(path + (size_t)st * T.N, path + (size_t)jj * T.N, W, q);
-                total += W;
-            }
-            first.push_back(total);
-            std::vector<uint8_t> valid;
-            if (total > 0) { if (int e = T.states_valid(q, valid)) return e; }
-            ++T.edge_batches;
-            for (int k = 0; k + 1 < (int)first.size(); ++k) {
-                bool all = true;
-                for (int w = first[k]; w < first[k + 1]; ++w) all = all && valid[w] != 0;
-                known[j + k] = all ? 1 : 0;
-            }
+        const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
+        auto it = known.find(key);
+        if (it != known.end()) {
+            if (it->second >= 0) return it->second == 1;
+            return true;                       // already queued in this run
         }
-        ok = known[j] == 1;
+        known.emplace(key, (int8_t)-1);
+        pending.emplace_back(a, b);
+        return true;
+    }
+    // one waypoint-parallel batch for every queued edge
+    int resolve()
+    {
+        std::vector<double> q;
+        std::vector<int> first(1, 0);
+        for (const auto& e : pending) {
+            const double* a = path + (size_t)e.first * T.N;
+            const double* b = path + (size_t)e.second * T.N;
+            const int W = T.waypoint_count(a, b);
+            T.append_waypoints(a, b, W, q);
+            first.push_back(first.back() + W);
+        }
+        std::vector<uint8_t> valid;
+        if (!q.empty()) { if (int e = T.states_valid(q, valid)) return e; }
+        ++T.edge_batches;
+        for (size_t k = 0; k < pending.size(); ++k) {
+            bool all = true;
+            for (int w = first[k]; w < first[k + 1]; ++w) all = all && valid[w] != 0;
+            known[((uint64_t)(uint32_t)pending[k].first << 32) | (uint32_t)pending[k].second] = all ? 1 : 0;
+        }
+        pending.clear();
         return SMPLX_OK;
     }
 };
 
 // shortcut.hpp:110-286 with the joint-space generator (post_processing.cpp:100-127), granularity 1
-int shortcut_path(PathTools& T, const std::vector<double>& pin, std::vector<double>& pout)
+void shortcut_run(PathTools& T, EdgeOracle& E, const std::vector<double>& pin, const std::vector<double>& accum,
+                  std::vector<double>& pout)
 {
     const int N = T.N;
     const int P = (int)(pin.size() / N);
     pout.clear();
-    if (P < 2) { pout = pin; return SMPLX_OK; }
     auto pt = [&](int i) { return pin.data() + (size_t)i * N; };
     auto push = [&](int i) { pout.insert(pout.end(), pt(i), pt(i) + N); };
-    std::vector<double> accum(P);
-    accum[0] = 0.0;
-    for (int i = 1; i < P; ++i) accum[i] = accum[i - 1] + T.distance(pt(i - 1), pt(i));
-    EdgeOracle E{T, pin.data(), P};
-    int err = SMPLX_OK;
     auto generate = [&](int a, int b, double& cost) {
-        bool ok = false;
-        if (int e = E.query(a, b, ok)) { err = e; return false; }
-        if (!ok) return false;
+        if (!E.query(a, b)) return false;
         cost = T.distance(pt(a), pt(b));
         return true;
     };
@@ -1783,7 +1783,7 @@ int shortcut_path(PathTools& T, const std::vector<double>& pin, std::vector<doub
         if (best_direct) push(best_last);
         else for (int i = start + 1; i <= best_last; ++i) push(i);
     };
-    while (end != P && err == SMPLX_OK) {
+    while (end != P) {
         bool improved = false;
         const int look = std::min(1, P - end - 1);
         if (look != 0) {
@@ -1810,9 +1810,23 @@ int shortcut_path(PathTools& T, const std::vector<double>& pin, std::vector<doub
             if (generate(start, end, cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
         }
     }
-    if (err) return err;
     emit_best();
-    return SMPLX_OK;
+}
+
+int shortcut_path(PathTools& T, const std::vector<double>& pin, std::vector<double>& pout)
+{
+    const int N = T.N;
+    const int P = (int)(pin.size() / N);
+    if (P < 2) { pout = pin; return SMPLX_OK; }
+    std::vector<double> accum(P);
+    accum[0] = 0.0;
+    for (int i = 1; i < P; ++i) accum[i] = accum[i - 1] + T.distance(pin.data() + (size_t)(i - 1) * N, pin.data() + (size_t)i * N);
+    EdgeOracle E{T, pin.data()};
+    for (;;) {
+        shortcut_run(T, E, pin, accum, pout);
+        if (E.pending.empty()) return SMPLX_OK;     // every answer this run used was a checked one
+        if (int e = E.resolve()) return e;
+    }
 }
 
 // post_processing.cpp:464-523 over CollisionSpace::interpolatePath (collision_space.cpp:583-612); *done = the
