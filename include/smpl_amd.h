@@ -85,7 +85,8 @@ typedef struct smplx_params {
                                          default 0: waypoint-parallel pipeline (same results, faster);
                                          bit 1: test hook -- a tiny work list, so that most edges take the
                                          deferred (fused) pass of the pipeline; bit 2: never use the single-launch
-                                         kernel for small batches (<= 256 states) */
+                                         kernel for small batches (<= 256 states); bit 3: generic kernels only, no
+                                         per-robot build (see smplx_space_specialized) */
 } smplx_params;
 
 /* RobotPlanningSpace::init + insertHeuristic (smpl/include/smpl/graph/robot_planning_space.h:68,89;
@@ -95,6 +96,13 @@ typedef struct smplx_params {
 int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const char* mprim_text,
                        const smplx_params* params, smplx_space** out);
 void smplx_space_destroy(smplx_space* s);
+/* 1 if the space runs kernels compiled for this robot: at creation the model's kinematic structure is turned into
+ * compile-time constants and the kernels are built against them with hiprtc (cached per process and on disk under
+ * $SMPLX_CACHE_DIR / $XDG_CACHE_HOME/smpl_amd / $HOME/.cache/smpl_amd); results are bit-identical to the generic
+ * kernels'.  0: generic kernels (note says why).  Env SMPLX_SPECIALIZE=0 disables, =2 makes a failed build an error. */
+int smplx_space_specialized(const smplx_space* s, char* note, int cap);
+/* the constants header the per-robot build is compiled against (returns the size needed, including the NUL) */
+int smplx_model_const_header(const smplx_model* m, char* out, int cap);
 int smplx_space_num_vars(const smplx_space* s);
 int smplx_space_num_prims(const smplx_space* s);
 int smplx_space_discretization(const smplx_space* s, int32_t* coord_vals, double* coord_deltas);

@@ -28,7 +28,7 @@ SYMBOLS = [
     "smplx_heuristic_batch", "smplx_bfs_size", "smplx_bfs_copy", "smplx_bfs_levels", "smplx_expand_batch",
     "smplx_expand_work_bytes", "smplx_expand_batch_device", "smplx_set_start", "smplx_start_id", "smplx_goal_id",
     "smplx_get_succs", "smplx_hint_frontier", "smplx_get_goal_heuristic", "smplx_num_states", "smplx_get_state",
-    "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_post_process_path", "smplx_profile_begin",
+    "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_post_process_path", "smplx_space_specialized", "smplx_model_const_header", "smplx_profile_begin",
     "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read", "smplx_plan_multi",
 ]
 
@@ -163,7 +163,7 @@ class Space:
     """ManipLattice + BfsHeuristic + CollisionSpace for one query, on one GPU."""
 
     def __init__(self, model: Model, grid: Grid, mprim_text: str, params, batch_states: int = 0, fused: bool = False,
-                 tiny_work_list: bool = False, no_small_kernel: bool = False):
+                 tiny_work_list: bool = False, no_small_kernel: bool = False, generic_kernels: bool = False):
         self.model, self.grid = model, grid
         P = Params()
         for i, r in enumerate(params.resolutions):
@@ -178,7 +178,8 @@ class Space:
         P.use_long_and_short = int(params.use_long_and_short)
         P.padding = 0.0
         P.batch_states = batch_states
-        P.reserved = (1 if fused else 0) | (2 if tiny_work_list else 0) | (4 if no_small_kernel else 0)
+        P.reserved = ((1 if fused else 0) | (2 if tiny_work_list else 0) | (4 if no_small_kernel else 0) |
+                      (8 if generic_kernels else 0))
         self.h = C.c_void_p()
         _chk(lib().smplx_space_create(model.h, grid.h, mprim_text.encode(), C.byref(P), C.byref(self.h)))
         self.N = lib().smplx_space_num_vars(self.h)
@@ -186,7 +187,7 @@ class Space:
 
     @classmethod
     def from_config(cls, cfg, batch_states: int = 0, xy_rotate=None, fused: bool = False, tiny_work_list: bool = False,
-                    no_small_kernel: bool = False):
+                    no_small_kernel: bool = False, generic_kernels: bool = False):
         g = Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
         m = Model(cfg.robot_text)
         p = cfg.params
@@ -194,7 +195,14 @@ class Space:
             import copy
             p = copy.copy(p)
             p.xy_rotate_by_var3 = xy_rotate
-        return cls(m, g, cfg.mprim, p, batch_states, fused, tiny_work_list, no_small_kernel)
+        return cls(m, g, cfg.mprim, p, batch_states, fused, tiny_work_list, no_small_kernel, generic_kernels)
+
+    def specialized(self):
+        """(True/False, note): whether the space runs the per-robot kernel build (smplx_space_specialized)."""
+        buf = C.create_string_buffer(4096)
+        lib().smplx_space_specialized.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        r = lib().smplx_space_specialized(self.h, buf, 4096)
+        return bool(r), buf.value.decode(errors="replace")
 
     def close(self):
         if self.h:

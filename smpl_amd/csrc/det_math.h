@@ -9,7 +9,9 @@
 // fixed polynomial below instead of libm / ocml (whose last bits differ).
 #pragma once
 
+#ifndef __HIPCC_RTC__   // hiprtc (per-robot specialisation, specialize.cpp) brings its own runtime declarations
 #include <math.h>
+#endif
 
 #if defined(__HIPCC__)
 #define SMPLX_HD __host__ __device__ inline __attribute__((always_inline))

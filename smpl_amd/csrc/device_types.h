@@ -4,7 +4,13 @@
 // the voxel grid, the BFS grid, the motion primitives and the goal.
 #pragma once
 
+#ifndef __HIPCC_RTC__   // hiprtc (per-robot specialisation, specialize.cpp) brings its own runtime declarations
 #include <stdint.h>
+#else
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#endif
 
 #define SMPLX_MAX_VARS 16
 #define SMPLX_MAX_JOINTS 40

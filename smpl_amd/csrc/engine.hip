@@ -21,6 +21,7 @@
 #include "device_types.h"
 #include "kernels.h"
 #include "model_compile.h"
+#include "specialize.h"
 
 namespace {
 
@@ -37,6 +38,13 @@ int set_error(int code, const std::string& msg)
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess)                                                                           \
             return set_error(SMPLX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+// launch of a model-dependent kernel: the per-robot build when the space has one (specialize.h)
+#define KLAUNCH(space, ID, kern, grid, block, lds, stream, ...)                                                   \
+    do {                                                                                                          \
+        hipError_t le_ = smplx::launch((space)->ks.k[smplx::ID], kern, grid, block, lds, stream, __VA_ARGS__);   \
+        if (le_ != hipSuccess) return set_error(SMPLX_E_HIP, std::string(#kern) + ": " + hipGetErrorString(le_)); \
     } while (0)
 
 template <class T>
@@ -168,6 +176,8 @@ struct smplx_space {
     DevBuf<double> b_q, b_q2, b_sq, b_xyz;
     DevBuf<unsigned char> b_flags, b_work;
     DevBuf<int32_t> b_coord, b_h, b_cost, b_lookups, b_way;
+    smplx::KernelSet ks;       // per-robot kernels (specialize.h), generic ones when params.reserved & 8 or SMPLX_SPECIALIZE=0
+    std::string specialize_note;   // why the per-robot build is absent, if it is
     bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
     bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
     int small_batch_max = 256;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
@@ -257,7 +267,7 @@ int run_heuristic(smplx_space* s, const double* q, int n, int32_t* h, double* xy
     if (int e = s->b_h.reserve(n)) return e;
     if (int e = s->b_xyz.reserve((size_t)n * 3)) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * N, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_heuristic, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->blob_bytes, s->stream, s->d_space, s->b_q.p, n,
+    KLAUNCH(s, K_HEURISTIC, k_heuristic, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->blob_bytes, s->stream, s->d_space, s->b_q.p, n,
                        s->b_h.p, s->b_xyz.p);
     HIP_TRY(hipGetLastError());
     if (h) HIP_TRY(hipMemcpyAsync(h, s->b_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
@@ -364,43 +374,43 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         const int32_t* deferred = s->d_minus_one;   // "no counter": the deferred pass scans its own flags
         // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
         const double* qsrc = zero_copy ? zero_copy->p_q.p : d_q;
-        hipLaunchKernelGGL(k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
+        KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
                            zero_copy ? zero_copy->p_flags.p : (unsigned char*)nullptr, zero_copy ? zero_copy->p_coord.p : (int32_t*)nullptr,
                            zero_copy ? zero_copy->p_sq.p : (double*)nullptr, zero_copy ? zero_copy->p_h.p : (int32_t*)nullptr);
-        hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, qsrc, norefs, B,
+        KLAUNCH(s, K_EXPAND, k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, qsrc, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
                            d_counters, (const int*)deferred, stab, state_q);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (ev) (void)hipEventRecord(ev[0], stream);
-        hipLaunchKernelGGL(k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_STATE_PREP, k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, stab, state_q);
         if (ev) (void)hipEventRecord(ev[1], stream);
-        hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_EXPAND, k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
                            d_counters, (const int*)nullptr, stab, state_q);
         if (ev) (void)hipEventRecord(ev[2], stream);
     } else {
         const size_t lm = s->blob_bytes;
-        hipLaunchKernelGGL(k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_PIPE_PREP, k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.work_count, stab, state_q);
-        hipLaunchKernelGGL(k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_PIPE_SETUP, k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
                            k.work, k.work_count, k.capacity, stab, state_q);
         if (ev) (void)hipEventRecord(ev[0], stream);
         const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK);
-        hipLaunchKernelGGL(k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_PIPE_CONFIGS, k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, k.work, k.work_count,
                            k.capacity);
         if (ev) (void)hipEventRecord(ev[1], stream);
-        hipLaunchKernelGGL(k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_PIPE_FINISH, k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, d_flags, d_coord, d_sq, d_h,
                            d_cost, d_lookups, d_counters, stab, state_q);
         if (ev) (void)hipEventRecord(ev[2], stream);
         // edges whose waypoints did not fit the work list (work_count[1] of them; normally none): every block of
         // this pass returns at once when the count is zero
-        hipLaunchKernelGGL(k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_EXPAND, k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
                            d_counters, (const int*)(k.work_count + 8 * 32), stab, state_q);
     }
@@ -738,6 +748,14 @@ int smplx_model_pairs(const smplx_model* m, int* pairs)
     return SMPLX_OK;
 }
 
+int smplx_model_const_header(const smplx_model* m, char* out, int cap)
+{
+    if (!m) return set_error(SMPLX_E_ARG, "null argument");
+    const std::string h = smplx::model_const_header(m->hm.dev);
+    if (out && cap > 0) { std::strncpy(out, h.c_str(), cap - 1); out[cap - 1] = 0; }
+    return (int)h.size() + 1;
+}
+
 int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const char* mprim_text, const smplx_params* params,
                        smplx_space** out)
 {
@@ -789,6 +807,18 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     hipError_t e;
     if ((e = hipGetDevice(&s->device)) != hipSuccess) return bail(e, "hipGetDevice");
     if ((e = hipStreamCreate(&s->stream)) != hipSuccess) return bail(e, "hipStreamCreate");
+    {
+        const char* env = getenv("SMPLX_SPECIALIZE");
+        smplx::generic_kernels(s->ks);
+        if (params->reserved & 8) s->specialize_note = "disabled by params.reserved bit 3";
+        else if (env && env[0] == '0') s->specialize_note = "disabled by SMPLX_SPECIALIZE=0";
+        else if (!smplx::specialized_kernels(s->model.dev, s->ks, s->specialize_note) && env && env[0] == '2') {
+            // SMPLX_SPECIALIZE=2: the per-robot build is required
+            const std::string msg = "kernel specialisation failed: " + s->specialize_note;
+            smplx_space_destroy(s);
+            return set_error(SMPLX_E_HIP, msg);
+        }
+    }
     if ((e = hipEventCreateWithFlags(&s->batch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
     const int dx = grid->n[0] + 2, dy = grid->n[1] + 2, dz = grid->n[2] + 2;
@@ -828,6 +858,13 @@ void smplx_space_destroy(smplx_space* s)
     delete s;
 }
 
+int smplx_space_specialized(const smplx_space* s, char* note, int cap)
+{
+    if (!s) return 0;
+    if (note && cap > 0) { std::strncpy(note, s->specialize_note.c_str(), cap - 1); note[cap - 1] = 0; }
+    return s->ks.specialized ? 1 : 0;
+}
+
 int smplx_space_num_vars(const smplx_space* s) { return s ? s->N : 0; }
 int smplx_space_num_prims(const smplx_space* s) { return s ? s->M : 0; }
 
@@ -850,7 +887,7 @@ int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* 
     if ((e = s->b_flags.reserve(n))) return e;
     if ((e = s->b_lookups.reserve(n))) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
+    KLAUNCH(s, K_STATE_VALID, k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
                        s->b_q.p, n, s->b_flags.p, s->b_lookups.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));
@@ -872,7 +909,7 @@ int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, 
     if ((e = s->b_way.reserve(n))) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, a, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->b_q2.p, b, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_edge_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
+    KLAUNCH(s, K_EDGE_VALID, k_edge_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
                        s->b_q.p, s->b_q2.p, n, s->b_flags.p, s->b_lookups.p, s->b_way.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));
@@ -918,7 +955,7 @@ int smplx_cc_sphere_positions(smplx_space* s, const double* q, int n, double* ou
     if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
     if ((e = s->b_sq.reserve(cnt))) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_sphere_positions, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream,
+    KLAUNCH(s, K_SPHERE_POSITIONS, k_sphere_positions, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream,
                        s->d_space, s->b_q.p, n, s->b_sq.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, s->b_sq.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, s->stream));

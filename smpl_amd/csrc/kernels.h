@@ -1,8 +1,10 @@
 // smpl_amd/csrc/kernels.h -- launch geometry and prototypes of the gfx950 kernels (kernels.hip)
 #pragma once
 
+#ifndef __HIPCC_RTC__   // hiprtc (per-robot specialisation, specialize.cpp) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "device_types.h"
 

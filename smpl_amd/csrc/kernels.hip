@@ -15,7 +15,9 @@
 // The sphere trees are staged in LDS; per-thread scratch (tree-root positions, saved link transforms,
 // DFS stack) lives in LDS in structure-of-arrays form (conflict-free: lane i touches word i).
 // Compile with -ffp-contract=off (arithmetic contract, det_math.h).
+#ifndef __HIPCC_RTC__   // hiprtc (per-robot specialisation, specialize.cpp) brings its own runtime declarations
 #include <hip/hip_runtime.h>
+#endif
 
 #include "det_math.h"
 #include "device_types.h"
@@ -372,6 +374,120 @@ __device__ __forceinline__ JointHead load_joint_head(const ModelLds* __restrict_
     return h;
 }
 
+#ifdef SMPLX_CONST_MODEL
+// ---------------------------------------------------------------------------------------------
+// Per-robot specialisation: the chain structure (joint kinds, origins, which link carries which tree, the
+// checked pairs) comes from compile-time constants (model_compile.cpp model_const_header), so the joint loop
+// is straight-line code: no joint records read from LDS, no kind dispatch, root positions and joint values in
+// registers.  Same operations in the same order as the generic path below: identical bits.
+// ---------------------------------------------------------------------------------------------
+#include SMPLX_CONST_MODEL
+
+struct ChainState {
+    double T[12];
+    double q[CM_NV];
+    double roots[3 * (CM_NT > 0 ? CM_NT : 1)];   // only the slots that lead a pair are ever touched
+    bool pair_hit, recheck_all;
+    unsigned long long pending;
+    int npending;
+};
+
+template <int T_, int K, int KEND>
+__device__ __forceinline__ void const_pairs(const ThreadLds& L, ChainState& C, const double rp[3])
+{
+    if constexpr (K < KEND) {
+        constexpr int ta = CM_PAIR_OTHER[K];
+        constexpr int sa = CM_ROOT_SLOT[ta];
+        constexpr bool a_first = ta < T_;
+        const double ax = C.roots[3 * sa + 0], ay = C.roots[3 * sa + 1], az = C.roots[3 * sa + 2];
+        const double dx = a_first ? rp[0] - ax : ax - rp[0];
+        const double dy = a_first ? rp[1] - ay : ay - rp[1];
+        const double dz = a_first ? rp[2] - az : az - rp[2];
+        const double cd2 = (dx * dx + dy * dy) + dz * dz;
+        constexpr double rr = a_first ? CM_ROOT_R[ta] + CM_ROOT_R[T_] : CM_ROOT_R[T_] + CM_ROOT_R[ta];
+        if (!(cd2 > rr * rr)) {
+            if constexpr (CM_ROOT_LEAF[ta] && CM_ROOT_LEAF[T_]) {
+                C.pair_hit = true;
+            } else {
+                if (C.npending < 4) {
+                    C.pending = (C.pending << 16) | (unsigned long long)((ta << 8) | T_);
+                    ++C.npending;
+                } else {
+                    C.recheck_all = true;
+                }
+            }
+        }
+        const_pairs<T_, K + 1, KEND>(L, C, rp);
+    }
+}
+
+// apply_joint_t with the origin's translation as literals: terms with an exactly-zero coefficient are dropped
+// (x*0 is +-0 and adding it changes no non-zero value)
+template <int J>
+__device__ __forceinline__ void apply_joint_const(double q, double T[12])
+{
+    constexpr int kind = CM_KIND[J];
+    constexpr double tx = CM_TX[J], ty = CM_TY[J], tz = CM_TZ[J];
+    if constexpr (CM_SRC[J] == SMPLX_SRC_ROOT) {
+        apply_joint_t(kind, tx, ty, tz, q, T, true);
+    } else {
+        if constexpr (tx != 0.0 || ty != 0.0 || tz != 0.0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double acc = 0.0;
+                bool have = false;
+                if constexpr (tx != 0.0) { acc = T[4 * i + 0] * tx; have = true; }
+                if constexpr (ty != 0.0) { acc = have ? acc + T[4 * i + 1] * ty : T[4 * i + 1] * ty; have = true; }
+                if constexpr (tz != 0.0) { acc = have ? acc + T[4 * i + 2] * tz : T[4 * i + 2] * tz; have = true; }
+                T[4 * i + 3] = acc + T[4 * i + 3];
+            }
+        }
+        if constexpr (kind != SMPLX_TK_FIXED_T) {
+            double s, c;
+            smplx_sincos(q, &s, &c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double a = T[4 * i + 0], b = T[4 * i + 1], d = T[4 * i + 2];
+                if constexpr (kind == SMPLX_TK_REV_X_T) { T[4 * i + 1] = b * c + d * s; T[4 * i + 2] = d * c - b * s; }
+                else if constexpr (kind == SMPLX_TK_REV_Y_T) { T[4 * i + 0] = a * c - d * s; T[4 * i + 2] = a * s + d * c; }
+                else { T[4 * i + 0] = a * c + b * s; T[4 * i + 1] = b * c - a * s; }
+            }
+        }
+    }
+}
+
+template <int J>
+__device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                            ChainState& C, int& lookups)
+{
+    if constexpr (J < CM_NJ) {
+        constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J], tree = CM_TREE[J];
+        if constexpr (src >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) C.T[i] = lds_d(L, L.slot_base + 12 * src + i);
+        }
+        double q = 0.0;
+        if constexpr (var >= 0) q = C.q[var];
+        if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J>(q, C.T);
+        else apply_joint(&M->joints[J], q, C.T, src == SMPLX_SRC_ROOT);
+        if constexpr (save >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = C.T[i];
+        }
+        if constexpr (tree >= 0) {
+            double rp[3];
+            if (!check_tree(M, L, g, tree, C.T, lookups, rp)) return false;
+            constexpr int slot = CM_ROOT_SLOT[tree];
+            if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
+            const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
+        }
+        return const_chain<J + 1>(M, L, g, C, lookups);
+    } else {
+        return true;
+    }
+}
+#endif   // SMPLX_CONST_MODEL
+
 // CollisionSpace::isStateValid for one configuration (collision_space.cpp:532-536 ->
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
@@ -388,7 +504,21 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
     lookups += (int)e.alpha; return true;
 #endif
     stage_config(M, L, e);
+#ifdef SMPLX_CONST_MODEL
+    {
+        ChainState C;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) C.T[i] = 0.0;
+#pragma unroll
+        for (int v = 0; v < CM_NV; ++v) C.q[v] = lds_d(L, L.q_base + v);
+        C.pair_hit = false; C.recheck_all = false; C.pending = 0; C.npending = 0;
+        if (!const_chain<0>(M, L, g, C, lookups)) return false;
+        pair_hit = C.pair_hit; recheck_all = C.recheck_all; pending = C.pending; npending = C.npending;
+    }
+    const int nj = 0;
+#else
     const int nj = M->njoints;
+#endif
     JointHead cur = load_joint_head(M, L, 0);
     for (int j = 0; j < nj; ++j) {
         // the next joint's record is requested from LDS now and consumed an iteration later, so its latency hides

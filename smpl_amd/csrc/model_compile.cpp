@@ -620,4 +620,48 @@ void fill_discretization(SmplxModelDev& m, const double* resolutions)
     }
 }
 
+
+std::string model_const_header(const SmplxModelDev& m)
+{
+    std::string o;
+    char buf[128];
+    auto ints = [&](const char* name, int n, auto get) {
+        o += "__device__ constexpr int ";
+        o += name;
+        snprintf(buf, sizeof buf, "[%d] = {", n > 0 ? n : 1);
+        o += buf;
+        for (int i = 0; i < n; ++i) { snprintf(buf, sizeof buf, "%d,", (int)get(i)); o += buf; }
+        if (n == 0) o += "0";
+        o += "};\n";
+    };
+    auto dbls = [&](const char* name, int n, auto get) {
+        o += "__device__ constexpr double ";
+        o += name;
+        snprintf(buf, sizeof buf, "[%d] = {", n > 0 ? n : 1);
+        o += buf;
+        for (int i = 0; i < n; ++i) { snprintf(buf, sizeof buf, "%a,", (double)get(i)); o += buf; }   // hex floats: exact
+        if (n == 0) o += "0";
+        o += "};\n";
+    };
+    snprintf(buf, sizeof buf, "#define CM_NJ %d\n#define CM_NT %d\n#define CM_NV %d\n", m.njoints, m.ntrees, m.nvars);
+    o += buf;
+    ints("CM_KIND", m.njoints, [&](int i) { return m.joints[i].kind; });
+    ints("CM_VAR", m.njoints, [&](int i) { return m.joints[i].var; });
+    ints("CM_SRC", m.njoints, [&](int i) { return m.joints[i].src; });
+    ints("CM_SAVE", m.njoints, [&](int i) { return m.joints[i].save_slot; });
+    ints("CM_TREE", m.njoints, [&](int i) { return m.joints[i].tree; });
+    dbls("CM_TX", m.njoints, [&](int i) { return m.joints[i].origin[3]; });
+    dbls("CM_TY", m.njoints, [&](int i) { return m.joints[i].origin[7]; });
+    dbls("CM_TZ", m.njoints, [&](int i) { return m.joints[i].origin[11]; });
+    ints("CM_TREE_ROOT", m.ntrees, [&](int t) { return m.tree_first[t + 1] - 1; });
+    ints("CM_ROOT_SLOT", m.ntrees, [&](int t) { return m.tree_root_slot[t]; });
+    ints("CM_ROOT_LEAF", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].left < 0; });
+    dbls("CM_ROOT_R", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].r; });
+    ints("CM_PAIR_FIRST", m.ntrees + 1, [&](int t) { return m.pair_first[t]; });
+    ints("CM_PAIR_OTHER", m.pair_first[m.ntrees], [&](int k) { return m.pair_other[k]; });
+    ints("CM_VAR_TYPE", m.nvars, [&](int v) { return m.var_type[v]; });
+    return o;
+}
+
 }  // namespace smplx
+

@@ -44,6 +44,10 @@ bool load_mprim_text(const char* text, const double* resolutions, int nvars, Hos
 // packed model for LDS staging (device_types.h SMPLX_BH_*); returns the byte count, 0 if it does not fit cap
 size_t pack_model_blob(const SmplxModelDev& m, unsigned char* out, size_t cap);
 
+// C++ text defining the chain structure of the model as compile-time constants (CM_* arrays): the input of the
+// per-robot specialisation of the collision kernel (kernels.hip, SMPLX_CONST_MODEL)
+std::string model_const_header(const SmplxModelDev& m);
+
 // ManipLattice::init discretisation (manip_lattice.cpp:125-139)
 void fill_discretization(SmplxModelDev& m, const double* resolutions);
 

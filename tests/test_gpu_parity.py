@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEG = scenes.DEG
 
 
-@pytest.fixture(scope="module", params=["pipeline", "fused", "small"])
+@pytest.fixture(scope="module", params=["pipeline", "fused", "small", "generic"])
 def ctx(small_cfg, request):
     from oracle_binding import Oracle
     from smpl_amd import capi
@@ -25,7 +25,12 @@ def ctx(small_cfg, request):
     o.set_order(chain=True)   # the kernel walks the sphere trees link by link (same booleans, see oracle)
     # "pipeline": four-kernel waypoint-parallel path forced for every batch size; "small": batches <= 256 states take
     # the single-launch kernel (the default policy); "fused": one thread per edge
-    s = capi.Space.from_config(small_cfg, fused=(request.param == "fused"), no_small_kernel=(request.param == "pipeline"))
+    # "generic": the kernels linked into the library; the other three run the per-robot hiprtc build of the same source
+    s = capi.Space.from_config(small_cfg, fused=(request.param == "fused"),
+                               no_small_kernel=(request.param in ("pipeline", "generic")),
+                               generic_kernels=(request.param == "generic"))
+    ok, note = s.specialized()
+    assert ok == (request.param != "generic"), "per-robot kernel build: " + note
     s.fused = request.param == "fused"
     o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
     s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
