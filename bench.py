@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
+    ap.add_argument("--generic-kernels", action="store_true", help="skip the per-robot hiprtc build (A/B runs)")
     args = ap.parse_args()
 
     import torch
@@ -95,7 +96,8 @@ def main():
     goal = list(cfg.goal)
     if rank > 0:   # independent queries: shift the goal by whole lattice cells, keep it reachable
         goal = [g + c * scenes.DEG for g, c in zip(goal, rank_goal_shift(rank))]
-    space = capi.Space.from_config(cfg, batch_states=args.batch)
+    space = capi.Space.from_config(cfg, batch_states=args.batch, generic_kernels=args.generic_kernels)
+    spec_ok, spec_note = space.specialized()
     ok, _ = space.state_valid_batch(np.array([goal]))
     if not ok[0]:
         goal = list(cfg.goal)
@@ -187,6 +189,7 @@ def main():
                    "batch_states": B, "primitives": M, "grid": args.grid, "queries": world,
                    "parallelism": f"query-shard x{world}" if world > 1 else "single query"},
         "valid_fraction": round(valid / max(evals, 1), 4),
+        "kernels": "per-robot hiprtc build" if spec_ok else "generic (" + spec_note[:200] + ")",
         "roofline": roofline,
     }
 
@@ -236,7 +239,7 @@ def main():
             o2.set_start(cfg.start)
             o2.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
             ro = o2.plan()
-            sp2 = capi.Space.from_config(cfg, batch_states=args.batch)
+            sp2 = capi.Space.from_config(cfg, batch_states=args.batch, generic_kernels=args.generic_kernels)
             sp2.set_goal_joint(goal, cfg.goal_tol)
             sp2.set_start(cfg.start)
             rg = sp2.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
@@ -281,7 +284,8 @@ def main():
         model_h = capi.Model(cfg.robot_text)
         for qi in range(nq):
             g = [a + c * scenes.DEG for a, c in zip(cfg.goal, rank_goal_shift(qi))]
-            sp = capi.Space(model_h, grid_h, cfg.mprim, cfg.params, args.batch)   # one scene, one robot, Q queries
+            sp = capi.Space(model_h, grid_h, cfg.mprim, cfg.params, args.batch,
+                            generic_kernels=args.generic_kernels)   # one scene, one robot, Q queries
             okq, _ = sp.state_valid_batch(np.array([g]))
             sp.set_goal_joint(g if okq[0] else cfg.goal, cfg.goal_tol)
             sp.set_start(cfg.start)

@@ -61,7 +61,7 @@ def lib():
     """Load (building in-tree if needed) the shared library."""
     global _lib
     if _lib is None:
-        path = _build.LIB
+        path = os.environ.get("SMPL_AMD_LIB", _build.LIB)   # override: kernel experiments (tools/)
         if not os.path.exists(path):
             _build.build()
         L = C.CDLL(path)

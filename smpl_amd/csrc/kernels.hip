@@ -804,7 +804,7 @@ __device__ __forceinline__ ModelLds setup_model_only(const SmplxSpaceDev* __rest
 // kernels
 // ---------------------------------------------------------------------------------------------
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it
 k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
              double* __restrict__ goal_dist, unsigned char* __restrict__ parent_valid, int* __restrict__ parent_lookups,
         const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
@@ -872,7 +872,7 @@ __device__ __forceinline__ bool mprim_active(const SmplxActionsDev& A, double go
     return A.enabled[type] && goal_dist <= A.thresh[type];
 }
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it
 k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
          const double* __restrict__ goal_dist, const unsigned char* __restrict__ parent_valid,
          const int* __restrict__ parent_lookups,
@@ -1146,7 +1146,7 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
     }
 }
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it
 k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
                const double* __restrict__ out_q, const int* __restrict__ edge_w, int* __restrict__ edge_lookups,
                unsigned char* __restrict__ edge_bad, int* __restrict__ state_lookups, unsigned char* __restrict__ state_bad,
@@ -1461,7 +1461,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     }
 }
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it
 k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq, const double* __restrict__ Bq, int n,
              unsigned char* __restrict__ out, int* __restrict__ out_lookups, int* __restrict__ out_waypoints)
 {
@@ -1479,7 +1479,7 @@ k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq,
     if (out_waypoints) out_waypoints[i] = W;
 }
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it
 k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, unsigned char* __restrict__ out,
               int* __restrict__ out_lookups)
 {
