@@ -423,12 +423,12 @@ __device__ __forceinline__ void const_pairs(const ThreadLds& L, ChainState& C, c
 
 // apply_joint_t with the origin's translation as literals: terms with an exactly-zero coefficient are dropped
 // (x*0 is +-0 and adding it changes no non-zero value)
-template <int J>
+template <int J, bool OnRoot>
 __device__ __forceinline__ void apply_joint_const(double q, double T[12])
 {
     constexpr int kind = CM_KIND[J];
     constexpr double tx = CM_TX[J], ty = CM_TY[J], tz = CM_TZ[J];
-    if constexpr (CM_SRC[J] == SMPLX_SRC_ROOT) {
+    if constexpr (OnRoot) {
         apply_joint_t(kind, tx, ty, tz, q, T, true);
     } else {
         if constexpr (tx != 0.0 || ty != 0.0 || tz != 0.0) {
@@ -468,7 +468,7 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         }
         double q = 0.0;
         if constexpr (var >= 0) q = C.q[var];
-        if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J>(q, C.T);
+        if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J, src == SMPLX_SRC_ROOT>(q, C.T);
         else apply_joint(&M->joints[J], q, C.T, src == SMPLX_SRC_ROOT);
         if constexpr (save >= 0) {
 #pragma unroll
@@ -484,6 +484,27 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         return const_chain<J + 1>(M, L, g, C, lookups);
     } else {
         return true;
+    }
+}
+
+// planning-link chain (planning_fk below) over the on-chain joints
+template <int J, bool First>
+__device__ __forceinline__ void const_planning_chain(const ModelLds* __restrict__ M, const double* __restrict__ q, double T[12])
+{
+    if constexpr (J < CM_NJ) {
+        if constexpr (CM_ON_CHAIN[J] != 0) {
+            constexpr int kind = CM_KIND[J], var = CM_VAR[J];
+            double qv = 0.0;
+            if constexpr (var >= 0) {
+                qv = q[var];
+                if constexpr (CM_VAR_TYPE[var] == SMPLX_JT_CONTINUOUS) qv = smplx_normalize_angle(qv);
+            }
+            if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J, First>(qv, T);
+            else apply_joint(&M->joints[J], qv, T, First);
+            const_planning_chain<J + 1, false>(M, q, T);
+        } else {
+            const_planning_chain<J + 1, First>(M, q, T);
+        }
     }
 }
 #endif   // SMPLX_CONST_MODEL
@@ -658,6 +679,11 @@ __device__ __forceinline__ void planning_fk(const ModelLds* __restrict__ M, cons
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = 0.0;
+#ifdef SMPLX_CONST_MODEL
+    const_planning_chain<0, true>(M, q, T);
+    p[0] = T[3]; p[1] = T[7]; p[2] = T[11];
+    return;
+#endif
     bool first = true;
     const int nj = M->njoints;
     for (int j = 0; j < nj; ++j) {

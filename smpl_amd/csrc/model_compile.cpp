@@ -650,6 +650,7 @@ std::string model_const_header(const SmplxModelDev& m)
     ints("CM_SRC", m.njoints, [&](int i) { return m.joints[i].src; });
     ints("CM_SAVE", m.njoints, [&](int i) { return m.joints[i].save_slot; });
     ints("CM_TREE", m.njoints, [&](int i) { return m.joints[i].tree; });
+    ints("CM_ON_CHAIN", m.njoints, [&](int i) { return m.joints[i].on_chain; });
     dbls("CM_TX", m.njoints, [&](int i) { return m.joints[i].origin[3]; });
     dbls("CM_TY", m.njoints, [&](int i) { return m.joints[i].origin[7]; });
     dbls("CM_TZ", m.njoints, [&](int i) { return m.joints[i].origin[11]; });
