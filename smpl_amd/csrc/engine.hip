@@ -404,15 +404,11 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, k.work, k.work_count,
                            k.capacity);
         if (ev) (void)hipEventRecord(ev[1], stream);
-        KLAUNCH(s, K_PIPE_FINISH, k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+        // edges whose waypoints did not fit the work list (normally none) are walked whole by their finish thread
+        KLAUNCH(s, K_PIPE_FINISH, k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, d_flags, d_coord, d_sq, d_h,
-                           d_cost, d_lookups, d_counters, stab, state_q);
+                           d_cost, d_lookups, d_counters, k.goal_dist, stab, state_q);
         if (ev) (void)hipEventRecord(ev[2], stream);
-        // edges whose waypoints did not fit the work list (work_count[1] of them; normally none): every block of
-        // this pass returns at once when the count is zero
-        KLAUNCH(s, K_EXPAND, k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
-                           k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
-                           d_counters, (const int*)(k.work_count + 8 * 32), stab, state_q);
     }
     HIP_TRY(hipGetLastError());
     return SMPLX_OK;

@@ -48,6 +48,7 @@ __global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int
                               const int* edge_lookups, const unsigned char* edge_bad, const int* state_lookups,
                               const unsigned char* state_bad, unsigned char* out_flags, int* out_coord, double* out_q,
                               int* out_h, int* out_cost, int* out_lookups, unsigned long long* counters,
+                              const double* goal_dist,
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist_out,
                               unsigned char* state_bad_out, int* state_lookups_out, unsigned char* out_flags, int* out_coord,

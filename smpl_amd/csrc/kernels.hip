@@ -476,10 +476,16 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         }
         if constexpr (tree >= 0) {
             double rp[3];
+#ifdef ABL_NO_TREES
+            rp[0] = C.T[3]; rp[1] = C.T[7]; rp[2] = C.T[11];
+#else
             if (!check_tree(M, L, g, tree, C.T, lookups, rp)) return false;
+#endif
             constexpr int slot = CM_ROOT_SLOT[tree];
             if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
+#ifndef ABL_NO_PAIRS
             const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
+#endif
         }
         return const_chain<J + 1>(M, L, g, C, lookups);
     } else {
@@ -898,6 +904,103 @@ __device__ __forceinline__ bool mprim_active(const SmplxActionsDev& A, double go
     return A.enabled[type] && goal_dist <= A.thresh[type];
 }
 
+// One (state, primitive) pair through the whole GetSuccs loop body in ONE thread (manip_lattice.cpp:1471-1535):
+// gating, successor joint values, limits, the edge's waypoints in the reference's order, discretisation, goal test,
+// heuristic.  parent_ok / parent_lk: result of the state's own check (waypoint 0 of every edge).
+struct EdgeTally { int flags, lookups, performed, evaluated; };
+
+__device__ __forceinline__ EdgeTally expand_edge(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxSpaceDev* __restrict__ S,
+                                                 const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid,
+                                                 const double* __restrict__ Q, const int64_t* __restrict__ refs, long long tid,
+                                                 const double* __restrict__ goal_dist, bool parent_ok, int parent_lk,
+                                                 unsigned char* __restrict__ out_flags, int* __restrict__ out_coord,
+                                                 double* __restrict__ out_q, int* __restrict__ out_h, int* __restrict__ out_cost,
+                                                 int* __restrict__ out_lookups)
+{
+    const SmplxActionsDev& A = S->actions;
+    const int nprims = A.nprims;
+    int flags = SMPLX_F_INACTIVE;
+    int lookups = 0;
+    int performed = 0;   // lookups this thread itself issued (waypoints >= 1)
+    int evaluated = 0;
+    {
+        const int si = (int)(tid / nprims);
+        const int pi = (int)(tid - (long long)si * nprims);
+        const int nv = M->nvars;
+        const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
+        double* sq = out_q + tid * nv;
+        int* sc = out_coord + tid * nv;
+        const SmplxBfsDev bfs = Sq->bfs;
+        const int type = A.type[pi];
+        int h = 0, cost = 0;
+        bool have_action = false;
+        if (mprim_active(A, goal_dist[si], type)) {
+            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+                // applyMotionPrimitive (manip_lattice_action_space.cpp:575-621)
+                double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
+                if (A.xy_rotate_by_var3 && nv > 3) {
+                    double s, c;
+                    smplx_sincos(parent[3], &s, &c);
+                    const double a0 = d0, a1 = d1;
+                    d0 = c * a0 + (-s) * a1;
+                    d1 = s * a0 + c * a1;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
+                    sq[v] = d + parent[v];
+                }
+                have_action = true;
+            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) {
+                for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];   // :551-559
+                have_action = true;
+            }
+        }
+        if (have_action) {
+            evaluated = 1;
+            flags = 0;
+            if (!check_joint_limits(M, sq)) {
+                flags = SMPLX_F_LIMITS;
+            } else {
+                int W = 0;
+                int lk = 0;
+                const bool ok = edge_valid(M, L, grid, parent, sq, true, parent_ok, lk, W);
+                lookups = lk;
+                performed = lk;
+                if (W > 0) lookups += parent_lk;   // waypoint 0, done once per state
+                if (!ok) {
+                    flags = SMPLX_F_COLLISION;
+                } else {
+                    for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
+                    bool is_goal;
+                    double p[3];
+                    planning_fk(M, sq, p);
+                    if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
+                        is_goal = true;
+                        for (int v = 0; v < nv; ++v)
+                            if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = false;
+                    } else {                                      // XYZ goal :1672-1687
+                        is_goal = fabs(p[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] &&
+                                  fabs(p[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
+                                  fabs(p[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
+                    }
+                    int c[3];
+                    world_to_cell(grid, p, c);
+                    h = bfs_cost_to_goal(bfs, c);
+                    cost = A.cost[pi];
+                    flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
+                }
+            }
+        }
+        out_flags[tid] = (unsigned char)flags;
+        out_h[tid] = h;
+        out_cost[tid] = cost;
+        out_lookups[tid] = lookups;
+    }
+    EdgeTally t;
+    t.flags = flags; t.lookups = lookups; t.performed = performed; t.evaluated = evaluated;
+    return t;
+}
+
 extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it
 k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
          const double* __restrict__ goal_dist, const unsigned char* __restrict__ parent_valid,
@@ -936,79 +1039,12 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
     int evaluated = 0;
     if (in_range) {
         const int si = (int)(tid / nprims);
-        const int pi = (int)(tid - (long long)si * nprims);
-        const int nv = M->nvars;
-        const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
-        double* sq = out_q + tid * nv;
-        int* sc = out_coord + tid * nv;
         const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;   // per-query goal and BFS grid
-        const SmplxBfsDev bfs = Sq->bfs;
-        const int type = A.type[pi];
-        int h = 0, cost = 0;
-        bool have_action = false;
-        if (mprim_active(A, goal_dist[si], type)) {
-            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
-                // applyMotionPrimitive (manip_lattice_action_space.cpp:575-621)
-                double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
-                if (A.xy_rotate_by_var3 && nv > 3) {
-                    double s, c;
-                    smplx_sincos(parent[3], &s, &c);
-                    const double a0 = d0, a1 = d1;
-                    d0 = c * a0 + (-s) * a1;
-                    d1 = s * a0 + c * a1;
-                }
-                for (int v = 0; v < nv; ++v) {
-                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
-                    sq[v] = d + parent[v];
-                }
-                have_action = true;
-            } else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) {
-                for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];   // :551-559
-                have_action = true;
-            }
-        }
-        if (have_action) {
-            evaluated = 1;
-            flags = 0;
-            if (!check_joint_limits(M, sq)) {
-                flags = SMPLX_F_LIMITS;
-            } else {
-                int W = 0;
-                int lk = 0;
-                // fused mode: parent_valid holds 1 = valid (k_state_prep); deferred pass: the pipeline's state_bad (1 = bad)
-                const bool pv = only_deferred ? parent_valid[si] == 0 : parent_valid[si] != 0;
-                const bool ok = edge_valid(M, L, grid, parent, sq, true, pv, lk, W);
-                lookups = lk;
-                performed = lk;
-                if (W > 0) lookups += parent_lookups[si];   // waypoint 0, done once per state by k_state_prep
-                if (!ok) {
-                    flags = SMPLX_F_COLLISION;
-                } else {
-                    for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
-                    bool is_goal;
-                    double p[3];
-                    planning_fk(M, sq, p);
-                    if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
-                        is_goal = true;
-                        for (int v = 0; v < nv; ++v)
-                            if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = false;
-                    } else {                                      // XYZ goal :1672-1687
-                        is_goal = fabs(p[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] &&
-                                  fabs(p[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
-                                  fabs(p[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
-                    }
-                    int c[3];
-                    world_to_cell(grid, p, c);
-                    h = bfs_cost_to_goal(bfs, c);
-                    cost = A.cost[pi];
-                    flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
-                }
-            }
-        }
-        out_flags[tid] = (unsigned char)flags;
-        out_h[tid] = h;
-        out_cost[tid] = cost;
-        out_lookups[tid] = lookups;
+        // fused mode: parent_valid holds 1 = valid (k_state_prep); deferred pass: the pipeline's state_bad (1 = bad)
+        const bool pv = only_deferred ? parent_valid[si] == 0 : parent_valid[si] != 0;
+        const EdgeTally t = expand_edge(M, L, S, Sq, grid, Q, refs, tid, goal_dist, pv, parent_lookups[si], out_flags, out_coord,
+                                        out_q, out_h, out_cost, out_lookups);
+        flags = t.flags; lookups = t.lookups; performed = t.performed; evaluated = t.evaluated;
     }
     // per-wave tallies: ballots instead of one atomic per lane
     if (counters) {
@@ -1233,11 +1269,12 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               const int* __restrict__ state_lookups, const unsigned char* __restrict__ state_bad,
               unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
               int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
-              unsigned long long* __restrict__ counters,
+              unsigned long long* __restrict__ counters, const double* __restrict__ goal_dist,
         const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const ModelLds Mv = setup_model_only(S, smem);
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv);   // scratch is only touched by edges that overflowed the work list
     const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
@@ -1255,8 +1292,16 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         const SmplxBfsDev bfs = Sq->bfs;
         if (pi == 0) { slk = state_lookups[si]; ncfg = 1; }
         int h = 0, cost = 0;
-        if (!(flags & (SMPLX_F_INACTIVE | SMPLX_F_DEFERRED))) evaluated = 1;   // deferred edges are tallied by the fused pass
-        if (flags == 0) {
+        bool deferred = false;
+        if (flags & SMPLX_F_DEFERRED) {
+            // the edge's waypoints did not fit the work list (normally none do not): this thread walks the whole edge
+            const EdgeTally t = expand_edge(M, L, S, Sq, grid, Q, refs, tid, goal_dist, state_bad[si] == 0, state_lookups[si],
+                                            out_flags, out_coord, out_q, out_h, out_cost, out_lookups);
+            flags = t.flags; lookups = t.lookups; performed = t.performed; evaluated = t.evaluated;
+            deferred = true;
+        }
+        if (!deferred && !(flags & SMPLX_F_INACTIVE)) evaluated = 1;
+        if (!deferred && flags == 0) {
             const int W = edge_w[tid];
             if (W > 0) ncfg += W - 1;
             performed = edge_lookups[tid];
@@ -1287,10 +1332,12 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                 flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
             }
         }
-        out_flags[tid] = (unsigned char)flags;
-        out_h[tid] = h;
-        out_cost[tid] = cost;
-        out_lookups[tid] = lookups;
+        if (!deferred) {
+            out_flags[tid] = (unsigned char)flags;
+            out_h[tid] = h;
+            out_cost[tid] = cost;
+            out_lookups[tid] = lookups;
+        }
     }
     if (counters) {
         const unsigned long long m_eval = __ballot(evaluated);
