@@ -189,7 +189,7 @@ def main():
                    "batch_states": B, "primitives": M, "grid": args.grid, "queries": world,
                    "parallelism": f"query-shard x{world}" if world > 1 else "single query"},
         "valid_fraction": round(valid / max(evals, 1), 4),
-        "kernels": "per-robot hiprtc build" if spec_ok else "generic (" + spec_note[:200] + ")",
+        "kernels": ("per-robot hiprtc build, " + spec_note[:120]) if spec_ok else "generic (" + spec_note[:200] + ")",
         "roofline": roofline,
     }
 

@@ -2,8 +2,13 @@
 #include "specialize.h"
 
 #include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <cstdio>
 #include <cstdlib>
@@ -12,9 +17,11 @@
 #include <mutex>
 #include <vector>
 
-#include "_embedded_sources.h"   // generated by smpl_amd/build.py: SRC_KERNELS_HIP, SRC_DET_MATH_H, SRC_DEVICE_TYPES_H, SRC_KERNELS_H
+#include "rtc_compile.h"
 #include "kernels.h"
 #include "model_compile.h"
+
+extern char** environ;
 
 namespace smplx {
 
@@ -23,9 +30,6 @@ namespace {
 const char* const kNames[K_COUNT] = {"k_state_prep", "k_expand", "k_pipe_prep", "k_pipe_setup", "k_pipe_configs",
                                      "k_pipe_finish", "k_small_batch", "k_edge_valid", "k_state_valid", "k_heuristic",
                                      "k_sphere_positions"};
-
-const char* const kOptions[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                                "-DSMPLX_CONST_MODEL=\"model_const.h\""};
 
 uint64_t fnv1a(uint64_t h, const std::string& s)
 {
@@ -71,54 +75,50 @@ void write_file_atomic(const std::string& path, const std::vector<char>& data)
     else (void)remove(tmp.c_str());
 }
 
-// extra -D options for diagnostic builds (tools/ablate.sh), e.g. SMPLX_RTC_DEFINES="-DABL_NO_TREES"
-std::vector<std::string> extra_defines()
-{
-    std::vector<std::string> out;
-    if (const char* e = getenv("SMPLX_RTC_DEFINES")) {
-        std::string cur;
-        for (const char* p = e;; ++p) {
-            if (*p == ' ' || *p == 0) { if (!cur.empty()) out.push_back(cur); cur.clear(); if (*p == 0) break; }
-            else cur += *p;
-        }
-    }
-    return out;
-}
+bool compile_via_helper(const std::string& header, const std::string& dir, uint64_t h, std::vector<char>& code, std::string& why);
 
-bool compile(const std::string& header, std::vector<char>& code, std::string& why)
+// Runs smplx_rtc (next to the shared library) as a child process: header file in, code object file out.
+bool compile_via_helper(const std::string& header, const std::string& dir, uint64_t h, std::vector<char>& code, std::string& why)
 {
-    const char* hs[4] = {SRC_DET_MATH_H, SRC_DEVICE_TYPES_H, SRC_KERNELS_H, header.c_str()};
-    const char* names[4] = {"det_math.h", "device_types.h", "kernels.h", "model_const.h"};
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, SRC_KERNELS_HIP, "kernels.hip", 4, hs, names) != HIPRTC_SUCCESS) {
-        why = "hiprtcCreateProgram failed";
-        return false;
+    Dl_info info;
+    if (!dladdr((const void*)&compile_via_helper, &info) || !info.dli_fname) { why = "dladdr failed"; return false; }
+    std::string exe = info.dli_fname;
+    const size_t cut = exe.find_last_of('/');
+    exe = (cut == std::string::npos ? std::string(".") : exe.substr(0, cut)) + "/smplx_rtc";
+    if (access(exe.c_str(), X_OK) != 0) { why = exe + " not found"; return false; }
+    char tag[64];
+    snprintf(tag, sizeof tag, "/%016llx.%ld", (unsigned long long)h, (long)getpid());
+    const std::string hpath = dir + tag + ".h", opath = dir + tag + ".out";
+    {
+        FILE* f = fopen(hpath.c_str(), "wb");
+        if (!f) { why = "cannot write " + hpath; return false; }
+        fwrite(header.data(), 1, header.size(), f);
+        fclose(f);
     }
-    std::vector<const char*> opts(kOptions, kOptions + sizeof(kOptions) / sizeof(kOptions[0]));
-    const std::vector<std::string> extra = extra_defines();
-    for (const std::string& x : extra) opts.push_back(x.c_str());
-    const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
-    if (r != HIPRTC_SUCCESS) {
-        size_t ls = 0;
-        (void)hiprtcGetProgramLogSize(prog, &ls);
-        std::string log(ls, 0);
-        if (ls) (void)hiprtcGetProgramLog(prog, &log[0]);
-        why = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 2000);
-        (void)hiprtcDestroyProgram(&prog);
-        return false;
+    std::vector<std::string> args = {exe, hpath, opath};
+    for (const std::string& x : rtc_extra_defines()) args.push_back(x);
+    std::vector<char*> argv;
+    for (std::string& a : args) argv.push_back(&a[0]);
+    argv.push_back(nullptr);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv.data(), environ);
+    bool ok = false;
+    if (rc != 0) {
+        why = std::string("posix_spawn: ") + strerror(rc);
+    } else {
+        int status = 0;
+        while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+        if (WIFEXITED(status) && WEXITSTATUS(status) == 0) ok = read_file(opath, code);
+        if (!ok) why = "smplx_rtc failed (status " + std::to_string(status) + ")";
     }
-    size_t cs = 0;
-    (void)hiprtcGetCodeSize(prog, &cs);
-    code.resize(cs);
-    const bool ok = cs > 0 && hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
-    (void)hiprtcDestroyProgram(&prog);
-    if (!ok) why = "hiprtcGetCode failed";
+    (void)remove(hpath.c_str());
+    (void)remove(opath.c_str());
     return ok;
 }
 
 struct Loaded {
     bool ok = false;
-    std::string why;
+    std::string why;   // failure reason, or on success where the code object came from
     hipFunction_t fn[K_COUNT] = {};
 };
 
@@ -147,8 +147,8 @@ bool specialized_kernels(const SmplxModelDev& model, KernelSet& ks, std::string&
     h = fnv1a(h, SRC_DET_MATH_H);
     h = fnv1a(h, SRC_DEVICE_TYPES_H);
     h = fnv1a(h, SRC_KERNELS_H);
-    for (const char* o : kOptions) h = fnv1a(h, o);
-    for (const std::string& x : extra_defines()) h = fnv1a(h, x);
+    for (const char* o : kRtcOptions) h = fnv1a(h, o);
+    for (const std::string& x : rtc_extra_defines()) h = fnv1a(h, x);
     int major = 0, minor = 0;
     (void)hiprtcVersion(&major, &minor);
     h = fnv1a(h, std::to_string(major) + "." + std::to_string(minor));
@@ -157,15 +157,34 @@ bool specialized_kernels(const SmplxModelDev& model, KernelSet& ks, std::string&
 
     std::lock_guard<std::mutex> lock(g_mutex);
     Loaded& L = g_loaded[{h, dev}];
-    if (!L.ok && L.why.empty()) {
+    if (!L.ok && L.why.empty()) {   // first request for this model on this device
         char name[64];
         snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
         const std::string path = cache_dir() + name;
         std::vector<char> code;
         bool have = read_file(path, code);
+        std::string how = "disk cache";
         if (!have) {
-            have = compile(header, code, L.why);
-            if (have) write_file_atomic(path, code);
+            // the helper executable compiles with the ROCm the library was built against; a host program may have
+            // loaded another hiprtc/comgr first (PyTorch bundles its own), whose code generation differs
+            std::string why_helper;
+            have = compile_via_helper(header, cache_dir(), h, code, why_helper);
+            how = "compiled by smplx_rtc";
+            if (have) {
+                write_file_atomic(path, code);
+            } else {
+                // no helper: whatever hiprtc this process has; cached under another name so that a later run with
+                // the helper does not pick it up
+                const std::string path2 = path.substr(0, path.size() - 6) + ".inproc.hsaco";
+                have = read_file(path2, code);
+                how = "disk cache (in-process build)";
+                if (!have) {
+                    have = rtc_compile(header, code, L.why);
+                    how = "compiled in-process (" + why_helper + ")";
+                    if (have) write_file_atomic(path2, code);
+                    else L.why = "helper: " + why_helper + "; in-process: " + L.why;
+                }
+            }
         }
         if (have) {
             hipModule_t mod = nullptr;
@@ -181,8 +200,10 @@ bool specialized_kernels(const SmplxModelDev& model, KernelSet& ks, std::string&
             }
         }
         if (!L.ok && L.why.empty()) L.why = "specialisation failed";
+        if (L.ok) L.why = how;
     }
-    if (!L.ok) { why = L.why; return false; }
+    why = L.why;
+    if (!L.ok) return false;
     for (int i = 0; i < K_COUNT; ++i) ks.k[i].fn = L.fn[i];
     ks.specialized = true;
     return true;
