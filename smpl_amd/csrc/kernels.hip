@@ -61,6 +61,31 @@ struct ThreadLds {
 __device__ __forceinline__ LDS_AS double& lds_d(const ThreadLds& L, int e) { return L.d[e * L.stride + threadIdx.x]; }
 __device__ __forceinline__ LDS_AS unsigned char& lds_b(const ThreadLds& L, int e) { return L.stk[e * L.stride + threadIdx.x]; }
 
+// Per-variable model data.  In the per-robot build (SMPLX_CONST_MODEL) these are literals and the loops over the
+// variables unroll; the generic kernels read the LDS copy of the model.
+#ifdef SMPLX_CONST_MODEL
+#include SMPLX_CONST_MODEL
+#define MV_NVARS(M) CM_NV
+#define MV_TYPE(M, v) CM_VAR_TYPE[v]
+#define MV_MIN(M, v) CM_VAR_MIN[v]
+#define MV_MAX(M, v) CM_VAR_MAX[v]
+#define MV_MIN_NORM(M, v) CM_VAR_MIN_NORM[v]
+#define MV_K(M, v) CM_VAR_K[v]
+#define MV_COORD_DELTA(M, v) CM_COORD_DELTA[v]
+#define MV_COORD_VALS(M, v) CM_COORD_VALS[v]
+#define MV_UNROLL _Pragma("unroll")
+#else
+#define MV_NVARS(M) (M)->nvars
+#define MV_TYPE(M, v) (M)->var_type[v]
+#define MV_MIN(M, v) (M)->var_min[v]
+#define MV_MAX(M, v) (M)->var_max[v]
+#define MV_MIN_NORM(M, v) (M)->var_min_norm[v]
+#define MV_K(M, v) (M)->var_k[v]
+#define MV_COORD_DELTA(M, v) (M)->coord_delta[v]
+#define MV_COORD_VALS(M, v) (M)->coord_vals[v]
+#define MV_UNROLL
+#endif
+
 // p = T * c   (robot_collision_state.h:576); ((a*x + b*y) + c*z) + t
 __device__ __forceinline__ void xform(const double T[12], const double c[3], double p[3])
 {
@@ -221,7 +246,7 @@ __device__ __forceinline__ int grid_d2(const SmplxGridDev& g, const double p[3])
 // (robot_motion_collision_model.h:221-247 diffs, 297-320 interpolate)
 __device__ __forceinline__ double edge_diff(const ModelLds* __restrict__ M, int v, double sv, double fv)
 {
-    return (M->var_type[v] == SMPLX_JT_CONTINUOUS) ? smplx_shortest_angle_diff(fv, sv) : fv - sv;
+    return (MV_TYPE(M, v) == SMPLX_JT_CONTINUOUS) ? smplx_shortest_angle_diff(fv, sv) : fv - sv;
 }
 
 // sphere tree vs voxel grid for the tree on the current link (collision_operations.h:105-164).
@@ -270,7 +295,8 @@ struct EdgeRef {
 // configuration (the slow path of the sphere-sphere pass re-reads them)
 __device__ __forceinline__ void stage_config(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e)
 {
-    const int nv = M->nvars;
+    const int nv = MV_NVARS(M);
+    MV_UNROLL
     for (int v = 0; v < nv; ++v) {
         const double sv = e.start[v];
         double q = sv;
@@ -381,7 +407,6 @@ __device__ __forceinline__ JointHead load_joint_head(const ModelLds* __restrict_
 // is straight-line code: no joint records read from LDS, no kind dispatch, root positions and joint values in
 // registers.  Same operations in the same order as the generic path below: identical bits.
 // ---------------------------------------------------------------------------------------------
-#include SMPLX_CONST_MODEL
 
 struct ChainState {
     double T[12];
@@ -641,12 +666,13 @@ __device__ __forceinline__ bool edge_valid(const ModelLds* __restrict__ M, const
 {
     // robot_motion_collision_model.cpp:371-407, .h:352-366, 173-181
     double motion = 0.0;
-    const int nv = M->nvars;
+    const int nv = MV_NVARS(M);
+    MV_UNROLL
     for (int v = 0; v < nv; ++v) {
-        const int ty = M->var_type[v];
+        const int ty = MV_TYPE(M, v);
         const double sv = start[v], fv = finish[v];
-        if (ty == SMPLX_JT_CONTINUOUS) motion += M->var_k[v] * fabs(smplx_shortest_angle_diff(fv, sv));
-        else if (ty == SMPLX_JT_REVOLUTE) motion += M->var_k[v] * fabs(fv - sv);
+        if (ty == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
+        else if (ty == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
         else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
     }
     int W = 0;
@@ -698,7 +724,7 @@ __device__ __forceinline__ void planning_fk(const ModelLds* __restrict__ M, cons
         double qv = 0.0;
         if (jt->var >= 0) {
             qv = q[jt->var];
-            if (M->var_type[jt->var] == SMPLX_JT_CONTINUOUS) qv = smplx_normalize_angle(qv);
+            if (MV_TYPE(M, jt->var) == SMPLX_JT_CONTINUOUS) qv = smplx_normalize_angle(qv);
         }
         apply_joint(jt, qv, T, first);
         first = false;
@@ -735,14 +761,15 @@ __device__ __forceinline__ int bfs_cost_to_goal(const SmplxBfsDev& b, const int 
 // KDLRobotModel::checkJointLimits (kdl_robot_model.cpp:173-189, 210-235)
 __device__ __forceinline__ bool check_joint_limits(const ModelLds* __restrict__ M, const double* __restrict__ q)
 {
-    const int nv = M->nvars;
+    const int nv = MV_NVARS(M);
+    MV_UNROLL
     for (int v = 0; v < nv; ++v) {
-        const double a_min = M->var_min[v], a_max = M->var_min_norm[v];
+        const double a_min = MV_MIN(M, v), a_max = MV_MIN_NORM(M, v);
         double a = q[v];
         if (fabs(a) > SMPLX_2PI) a = fmod(a, SMPLX_2PI);
         while (a > a_max) a -= SMPLX_2PI;
         while (a < a_min) a += SMPLX_2PI;
-        if (a < M->var_min[v] || a > M->var_max[v]) return false;
+        if (a < MV_MIN(M, v) || a > MV_MAX(M, v)) return false;
     }
     return true;
 }
@@ -750,16 +777,16 @@ __device__ __forceinline__ bool check_joint_limits(const ModelLds* __restrict__ 
 // ManipLattice::stateToCoord for one variable (manip_lattice.cpp:1263-1289)
 __device__ __forceinline__ int var_to_coord(const ModelLds* __restrict__ M, int v, double x)
 {
-    const double delta = M->coord_delta[v];
-    const int ty = M->var_type[v];
+    const double delta = MV_COORD_DELTA(M, v);
+    const int ty = MV_TYPE(M, v);
     if (ty == SMPLX_JT_CONTINUOUS) {
         const double pos = smplx_normalize_angle_positive(x);
         int c = (int)((pos + delta * 0.5) / delta);
-        if (c == M->coord_vals[v]) c = 0;
+        if (c == MV_COORD_VALS(M, v)) c = 0;
         return c;
     }
     // bounded variables (every non-continuous variable of the plain-text model has limits)
-    return (int)(((x - M->var_min[v]) / delta) + 0.5);
+    return (int)(((x - MV_MIN(M, v)) / delta) + 0.5);
 }
 
 // Cooperative copy of the packed model (a few KB) into LDS in 16-byte pieces, all loads of a thread issued before
@@ -827,9 +854,16 @@ __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__
 // kernels that only need the model (no per-thread scratch)
 __device__ __forceinline__ ModelLds setup_model_only(const SmplxSpaceDev* __restrict__ S, unsigned char* smem)
 {
+#if defined(SMPLX_CONST_MODEL) && !CM_NEEDS_JOINTS
+    // per-robot build: the planning-link chain and the per-variable data are literals, nothing is read from LDS
+    ModelLds M = {};
+    M.njoints = CM_NJ; M.nvars = CM_NV; M.ntrees = CM_NT;
+    return M;
+#else
     ModelLds M = stage_model(S, smem);
     __syncthreads();
     return M;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -849,7 +883,7 @@ k_state_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= B) return;
     const SmplxBfsDev bfs = (stab ? stab[state_q[i]] : S)->bfs;   // per-query data in a cross-query batch
-    const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
+    const double* q = Q + (refs ? refs[i] : (int64_t)i) * MV_NVARS(M);
     double p[3];
     planning_fk(M, q, p);
     // BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138)
@@ -926,7 +960,7 @@ __device__ __forceinline__ EdgeTally expand_edge(const ModelLds* __restrict__ M,
     {
         const int si = (int)(tid / nprims);
         const int pi = (int)(tid - (long long)si * nprims);
-        const int nv = M->nvars;
+        const int nv = MV_NVARS(M);
         const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
         double* sq = out_q + tid * nv;
         int* sc = out_coord + tid * nv;
@@ -945,12 +979,14 @@ __device__ __forceinline__ EdgeTally expand_edge(const ModelLds* __restrict__ M,
                     d0 = c * a0 + (-s) * a1;
                     d1 = s * a0 + c * a1;
                 }
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) {
                     const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
                     sq[v] = d + parent[v];
                 }
                 have_action = true;
             } else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) {
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];   // :551-559
                 have_action = true;
             }
@@ -970,12 +1006,14 @@ __device__ __forceinline__ EdgeTally expand_edge(const ModelLds* __restrict__ M,
                 if (!ok) {
                     flags = SMPLX_F_COLLISION;
                 } else {
+                    MV_UNROLL
                     for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
                     bool is_goal;
                     double p[3];
                     planning_fk(M, sq, p);
                     if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
                         is_goal = true;
+                        MV_UNROLL
                         for (int v = 0; v < nv; ++v)
                             if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = false;
                     } else {                                      // XYZ goal :1672-1687
@@ -1087,7 +1125,7 @@ k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, c
     if (i <= SMPLX_WORK_SHARDS) work_count[i * SMPLX_SHARD_STRIDE] = 0;   // shard counters + deferred count
     if (i >= B) return;
     const SmplxBfsDev bfs = (stab ? stab[state_q[i]] : S)->bfs;
-    const double* q = Q + (refs ? refs[i] : (int64_t)i) * M->nvars;
+    const double* q = Q + (refs ? refs[i] : (int64_t)i) * MV_NVARS(M);
     double p[3];
     planning_fk(M, q, p);
     int c[3];
@@ -1116,7 +1154,7 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
     if (in_range) {
         const int si = (int)(tid / nprims);
         const int pi = (int)(tid - (long long)si * nprims);
-        const int nv = M->nvars;
+        const int nv = MV_NVARS(M);
         const double* parent = Q + (refs ? refs[si] : (int64_t)si) * nv;
         double* sq = out_q + tid * nv;
         const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
@@ -1133,12 +1171,14 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
                     d0 = c * a0 + (-s) * a1;
                     d1 = s * a0 + c * a1;
                 }
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) {
                     const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
                     sq[v] = d + parent[v];
                 }
                 have_action = true;
             } else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) {
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];
                 have_action = true;
             }
@@ -1149,11 +1189,12 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
                 flags = SMPLX_F_LIMITS;
             } else {
                 double motion = 0.0;
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) {
-                    const int ty = M->var_type[v];
+                    const int ty = MV_TYPE(M, v);
                     const double sv = parent[v], fv = sq[v];
-                    if (ty == SMPLX_JT_CONTINUOUS) motion += M->var_k[v] * fabs(smplx_shortest_angle_diff(fv, sv));
-                    else if (ty == SMPLX_JT_REVOLUTE) motion += M->var_k[v] * fabs(fv - sv);
+                    if (ty == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
+                    else if (ty == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
                     else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
                 }
                 if (motion != 0.0) {
@@ -1231,7 +1272,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const int nprims = S->actions.nprims;
-    const int nv = M->nvars;
+    const int nv = MV_NVARS(M);
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * BLOCK) {
         EdgeRef e;
         int lk = 0;
@@ -1263,7 +1304,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     }
 }
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // holds the whole-edge walk for overflowed edges: keep it at 2 waves per SIMD
 k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
               const int* __restrict__ edge_w, const int* __restrict__ edge_lookups, const unsigned char* __restrict__ edge_bad,
               const int* __restrict__ state_lookups, const unsigned char* __restrict__ state_bad,
@@ -1273,9 +1314,6 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv);   // scratch is only touched by edges that overflowed the work list
-    const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
     const int nprims = A.nprims;
@@ -1283,11 +1321,25 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const bool in_range = tid < (long long)B * nprims;
     int flags = SMPLX_F_INACTIVE, lookups = 0, performed = 0, evaluated = 0;
     int ncfg = 0, slk = 0;   // configurations k_pipe_configs checked for this edge / lookups of the state's own check
+    if (in_range) flags = out_flags[tid];
+    // the model and the per-thread scratch are only needed by edges that overflowed the work list (normally none)
+    ModelLds Mv;
+    ThreadLds L;
+#if defined(SMPLX_CONST_MODEL) && !CM_NEEDS_JOINTS
+    if (__syncthreads_or(flags & SMPLX_F_DEFERRED)) {
+        L = setup_lds(S, smem, &Mv);
+    } else {
+        Mv = setup_model_only(S, smem);
+        L = ThreadLds();
+    }
+#else
+    L = setup_lds(S, smem, &Mv);
+#endif
+    const ModelLds* M = &Mv;
     if (in_range) {
         const int si = (int)(tid / nprims);
         const int pi = (int)(tid - (long long)si * nprims);
-        const int nv = M->nvars;
-        flags = out_flags[tid];
+        const int nv = MV_NVARS(M);
         const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
         const SmplxBfsDev bfs = Sq->bfs;
         if (pi == 0) { slk = state_lookups[si]; ncfg = 1; }
@@ -1312,12 +1364,14 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             } else {
                 const double* sq = out_q + tid * nv;
                 int* sc = out_coord + tid * nv;
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
                 double p[3];
                 planning_fk(M, sq, p);
                 bool is_goal;
                 if (Sq->goal.type == SMPLX_GOAL_JOINT) {
                     is_goal = true;
+                    MV_UNROLL
                     for (int v = 0; v < nv; ++v)
                         if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = false;
                 } else {
@@ -1384,7 +1438,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const int si = blockIdx.x;
     const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
     const SmplxBfsDev bfs = Sq->bfs;
-    const int nprims = A.nprims, nv = M->nvars;
+    const int nprims = A.nprims, nv = MV_NVARS(M);
     const int t = threadIdx.x;
     const int pi = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
     const bool edge_thread = pi < nprims;
@@ -1431,11 +1485,13 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                     d0 = c * a0 + (-s) * a1;
                     d1 = s * a0 + c * a1;
                 }
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) {
                     const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
                     sq[v] = d + parent[v];
                 }
             } else {
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];
             }
         }
@@ -1445,11 +1501,12 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         limits_ok = check_joint_limits(M, sq);
         if (limits_ok) {
             double motion = 0.0;
+            MV_UNROLL
             for (int v = 0; v < nv; ++v) {
-                const int ty = M->var_type[v];
+                const int ty = MV_TYPE(M, v);
                 const double sv = parent[v], fv = sq[v];
-                if (ty == SMPLX_JT_CONTINUOUS) motion += M->var_k[v] * fabs(smplx_shortest_angle_diff(fv, sv));
-                else if (ty == SMPLX_JT_REVOLUTE) motion += M->var_k[v] * fabs(fv - sv);
+                if (ty == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
+                else if (ty == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
                 else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
             }
             if (motion != 0.0) {
@@ -1474,11 +1531,13 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             }
         } else {
             int* sc = out_coord + eid * nv;
+            MV_UNROLL
             for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
             double p[3];
             planning_fk(M, sq, p);
             if (Sq->goal.type == SMPLX_GOAL_JOINT) {
                 is_goal = 1;
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v)
                     if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = 0;
             } else {
@@ -1528,6 +1587,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             if (flags & SMPLX_F_VALID) {
                 host_h[eid] = hh;
                 const int* sc = out_coord + eid * nv;
+                MV_UNROLL
                 for (int v = 0; v < nv; ++v) { host_coord[eid * nv + v] = sc[v]; host_q[eid * nv + v] = sq[v]; }
             }
         }
@@ -1546,7 +1606,7 @@ k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq,
     if (i >= n) return;
     int lk = 0, W = 0;
     const SmplxGridDev grid = S->grid;
-    const bool ok = edge_valid(M, L, grid, Aq + (size_t)i * M->nvars, Bq + (size_t)i * M->nvars, false, true, lk, W);
+    const bool ok = edge_valid(M, L, grid, Aq + (size_t)i * MV_NVARS(M), Bq + (size_t)i * MV_NVARS(M), false, true, lk, W);
     out[i] = ok ? 1 : 0;
     if (out_lookups) out_lookups[i] = lk;
     if (out_waypoints) out_waypoints[i] = W;
@@ -1563,7 +1623,7 @@ k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     EdgeRef e;
-    e.start = Q + (size_t)i * M->nvars; e.finish = e.start; e.alpha = 0.0;
+    e.start = Q + (size_t)i * MV_NVARS(M); e.finish = e.start; e.alpha = 0.0;
     int lk = 0;
     const SmplxGridDev grid = S->grid;
     const bool ok = config_valid(M, L, grid, e, lk);
@@ -1581,7 +1641,7 @@ k_heuristic(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, i
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     double p[3];
-    planning_fk(M, Q + (size_t)i * M->nvars, p);
+    planning_fk(M, Q + (size_t)i * MV_NVARS(M), p);
     int c[3];
     world_to_cell(S->grid, p, c);
     out_h[i] = bfs_cost_to_goal(S->bfs, c);
@@ -1598,7 +1658,7 @@ k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict
     const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const double* q = Q + (size_t)i * M->nvars;
+    const double* q = Q + (size_t)i * MV_NVARS(M);
     double T[12];
     for (int k = 0; k < 12; ++k) T[k] = 0.0;
     for (int j = 0; j < M->njoints; ++j) {

@@ -661,6 +661,20 @@ std::string model_const_header(const SmplxModelDev& m)
     ints("CM_PAIR_FIRST", m.ntrees + 1, [&](int t) { return m.pair_first[t]; });
     ints("CM_PAIR_OTHER", m.pair_first[m.ntrees], [&](int k) { return m.pair_other[k]; });
     ints("CM_VAR_TYPE", m.nvars, [&](int v) { return m.var_type[v]; });
+    dbls("CM_VAR_MIN", m.nvars, [&](int v) { return m.var_min[v]; });
+    dbls("CM_VAR_MAX", m.nvars, [&](int v) { return m.var_max[v]; });
+    dbls("CM_VAR_MIN_NORM", m.nvars, [&](int v) { return m.var_min_norm[v]; });
+    dbls("CM_VAR_K", m.nvars, [&](int v) { return m.var_k[v]; });
+    // discretisation of the planning space the model is bound to (fill_discretization)
+    dbls("CM_COORD_DELTA", m.nvars, [&](int v) { return m.coord_delta[v]; });
+    ints("CM_COORD_VALS", m.nvars, [&](int v) { return m.coord_vals[v]; });
+    {
+        // joints whose transform has no literal form still read their record from the LDS copy of the model
+        int needs = 0;
+        for (int i = 0; i < m.njoints; ++i) if (m.joints[i].kind < SMPLX_TK_FIXED_T) needs = 1;
+        snprintf(buf, sizeof buf, "#define CM_NEEDS_JOINTS %d\n", needs);
+        o += buf;
+    }
     return o;
 }
 
