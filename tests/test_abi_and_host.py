@@ -98,3 +98,44 @@ def test_mprim_text_round_trip_against_oracle(small_cfg):
     o = Oracle(small_cfg)
     assert o.M == 25            # 3 adaptive slots + (4 long + 7 short) x 2 (converse), pr2.mprim layout
     assert o.N == 7
+
+
+# --- per-robot kernel build (csrc/specialize.cpp): host-side pieces, no GPU ---
+
+def _const_header(robot_text):
+    import ctypes as C
+    from smpl_amd import capi
+    L = capi.lib()
+    m = capi.Model(robot_text)
+    L.smplx_model_const_header.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    n = L.smplx_model_const_header(m.h, None, 0)
+    buf = C.create_string_buffer(n)
+    assert L.smplx_model_const_header(m.h, buf, n) == n
+    return buf.value.decode()
+
+
+def test_model_constants_header_describes_the_chain(small_cfg):
+    h = _const_header(small_cfg.robot_text)
+    assert "#define CM_NJ 13" in h and "#define CM_NV 7" in h and "#define CM_NT 8" in h
+    # 7 revolute joints with identity-rotation origins (kinds 7..9), fixed ones 6: every transform has a literal form
+    assert "#define CM_NEEDS_JOINTS 0" in h
+    kinds = [int(x) for x in h.split("CM_KIND[13] = {")[1].split("}")[0].strip(",").split(",")]
+    assert sorted(set(kinds)) == [6, 7, 8, 9] and sum(k != 6 for k in kinds) == 7
+    # doubles are hex floats: the compiled constants are the host model's bits
+    assert "0x1." in h.split("CM_VAR_K")[1].split("\n")[0]
+
+
+@pytest.mark.parametrize("robot", ["arm7", "dual14"])
+def test_per_robot_source_compiles_for_gfx950_with_the_helper(robot, tmp_path):
+    """What smplx_space_create does on the GPU box, minus the module load: header -> smplx_rtc -> code object."""
+    import subprocess
+    from smpl_amd import build, scenes
+    text = scenes.arm7_robot() if robot == "arm7" else scenes.dual_arm14_robot()
+    hp, op = tmp_path / "model_const.h", tmp_path / "k.hsaco"
+    hp.write_text(_const_header(text))
+    subprocess.check_call([build.RTC, str(hp), str(op)], timeout=600)
+    code = op.read_bytes()
+    assert code[:4] == b"\x7fELF"
+    for k in ("k_pipe_prep", "k_pipe_setup", "k_pipe_configs", "k_pipe_finish", "k_small_batch", "k_expand", "k_state_valid",
+              "k_edge_valid", "k_heuristic", "k_sphere_positions", "k_state_prep"):
+        assert k.encode() in code
