@@ -481,6 +481,66 @@ __device__ __forceinline__ void apply_joint_const(double q, double T[12])
     }
 }
 
+// check_tree with the root sphere as literals: in free space the root clears and nothing is read from LDS; a root
+// that does not clear hands over to the generic traversal at its children (larger child first, as check_tree does)
+template <int T_>
+__device__ __forceinline__ bool check_tree_const(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                                 const double T[12], int& lookups, double root_p[3])
+{
+    constexpr double cx = CM_ROOT_CX[T_], cy = CM_ROOT_CY[T_], cz = CM_ROOT_CZ[T_];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // ((a*x + b*y) + c*z) + t with exactly-zero coefficients dropped (see apply_joint_const)
+        double acc = 0.0;
+        bool have = false;
+        if constexpr (cx != 0.0) { acc = T[4 * i + 0] * cx; have = true; }
+        if constexpr (cy != 0.0) { acc = have ? acc + T[4 * i + 1] * cy : T[4 * i + 1] * cy; have = true; }
+        if constexpr (cz != 0.0) { acc = have ? acc + T[4 * i + 2] * cz : T[4 * i + 2] * cz; have = true; }
+        root_p[i] = have ? acc + T[4 * i + 3] : T[4 * i + 3];
+    }
+    ++lookups;
+#ifdef ABL_NO_LOOKUP
+    const int d2 = 60000 + (int)(root_p[0] * 0.0);
+#else
+    const int d2 = grid_d2(g, root_p);
+#endif
+    if (!(d2 < CM_ROOT_THR[T_])) return true;
+    if constexpr (CM_ROOT_LEFT[T_] < 0) {
+        return false;
+    } else {
+        // descend: the same loop as check_tree, entered below the root
+        int sp = 0;
+        int node;
+        {
+            const double rl = L.nodes[CM_ROOT_LEFT[T_]].r, rr = L.nodes[CM_ROOT_RIGHT[T_]].r;
+            if (rl > rr) { lds_b(L, sp++) = (unsigned char)CM_ROOT_RIGHT[T_]; node = CM_ROOT_LEFT[T_]; }
+            else { lds_b(L, sp++) = (unsigned char)CM_ROOT_LEFT[T_]; node = CM_ROOT_RIGHT[T_]; }
+        }
+        while (true) {
+            const LDS_AS SmplxNode& nd = L.nodes[node];
+            double c[3] = {nd.c[0], nd.c[1], nd.c[2]};
+            double p[3];
+            xform(T, c, p);
+            ++lookups;
+#ifdef ABL_NO_LOOKUP
+            const int dd = 60000 + (int)(p[0] * 0.0);
+#else
+            const int dd = grid_d2(g, p);
+#endif
+            if (dd < nd.thr) {
+                if (nd.left < 0) return false;
+                const double rl = L.nodes[nd.left].r, rr = L.nodes[nd.right].r;
+                if (rl > rr) { lds_b(L, sp++) = (unsigned char)nd.right; node = nd.left; }
+                else { lds_b(L, sp++) = (unsigned char)nd.left; node = nd.right; }
+                continue;
+            }
+            if (sp == 0) break;
+            node = lds_b(L, --sp);
+        }
+        return true;
+    }
+}
+
 template <int J>
 __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                             ChainState& C, int& lookups)
@@ -504,7 +564,7 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
 #ifdef ABL_NO_TREES
             rp[0] = C.T[3]; rp[1] = C.T[7]; rp[2] = C.T[11];
 #else
-            if (!check_tree(M, L, g, tree, C.T, lookups, rp)) return false;
+            if (!check_tree_const<tree>(M, L, g, C.T, lookups, rp)) return false;
 #endif
             constexpr int slot = CM_ROOT_SLOT[tree];
             if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }

@@ -658,6 +658,13 @@ std::string model_const_header(const SmplxModelDev& m)
     ints("CM_ROOT_SLOT", m.ntrees, [&](int t) { return m.tree_root_slot[t]; });
     ints("CM_ROOT_LEAF", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].left < 0; });
     dbls("CM_ROOT_R", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].r; });
+    dbls("CM_ROOT_CX", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].c[0]; });
+    dbls("CM_ROOT_CY", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].c[1]; });
+    dbls("CM_ROOT_CZ", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].c[2]; });
+    // bound to the grid the space was created on (sphere_threshold)
+    ints("CM_ROOT_THR", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].thr; });
+    ints("CM_ROOT_LEFT", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].left; });
+    ints("CM_ROOT_RIGHT", m.ntrees, [&](int t) { return m.nodes[m.tree_first[t + 1] - 1].right; });
     ints("CM_PAIR_FIRST", m.ntrees + 1, [&](int t) { return m.pair_first[t]; });
     ints("CM_PAIR_OTHER", m.pair_first[m.ntrees], [&](int k) { return m.pair_other[k]; });
     ints("CM_VAR_TYPE", m.nvars, [&](int v) { return m.var_type[v]; });
