@@ -325,7 +325,7 @@ struct ExpandWork {
     int32_t* edge_lookups;
     unsigned char* edge_bad;
     int32_t* work_count;
-    unsigned int* work;
+    unsigned long long* work;   // 64-bit items: edge | waypoint << 32 | waypoint count << 48
     int capacity;
 };
 
@@ -335,7 +335,7 @@ size_t expand_work_bytes(int B, int M)
 {
     const size_t b = (size_t)B, bm = (size_t)B * M;
     return align256(b * 8) + align256(b * 4) + align256(b) + align256(bm * 4) + align256(bm * 4) + align256(bm) + 2048 +
-           align256(bm * 16 * 4);
+           align256(bm * 16 * 8);
 }
 
 ExpandWork carve_work(void* base, int B, int M)
@@ -350,7 +350,7 @@ ExpandWork carve_work(void* base, int B, int M)
     k.edge_lookups = (int32_t*)w; w += align256(bm * 4);
     k.edge_bad = w; w += align256(bm);
     k.work_count = (int32_t*)w; w += 2048;   // 8 shard counters + deferred count, one 128-byte line each
-    k.work = (unsigned int*)w;
+    k.work = (unsigned long long*)w;
     k.capacity = (int)std::min<size_t>(bm * 16, (size_t)1 << 30) / 8 * 8;
     return k;
 }

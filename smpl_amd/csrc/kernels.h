@@ -38,12 +38,12 @@ __global__ void k_pipe_prep(const SmplxSpaceDev* S, const double* Q, const int64
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_setup(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
                              unsigned char* out_flags, double* out_q, int* edge_w, int* edge_lookups,
-                             unsigned char* edge_bad, int* state_lookups, unsigned char* state_bad, unsigned int* work,
+                             unsigned char* edge_bad, int* state_lookups, unsigned char* state_bad, unsigned long long* work,
                              int* work_count, int capacity,
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_configs(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* out_q,
                                const int* edge_w, int* edge_lookups, unsigned char* edge_bad, int* state_lookups,
-                               unsigned char* state_bad, const unsigned int* work, const int* work_count, int capacity);
+                               unsigned char* state_bad, const unsigned long long* work, const int* work_count, int capacity);
 __global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const int* edge_w,
                               const int* edge_lookups, const unsigned char* edge_bad, const int* state_lookups,
                               const unsigned char* state_bad, unsigned char* out_flags, int* out_coord, double* out_q,

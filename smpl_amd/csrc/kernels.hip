@@ -1167,8 +1167,10 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
 // edge can exceed the reference's; for valid edges it is identical.
 // ---------------------------------------------------------------------------------------------
 
-#define SMPLX_WP_BITS 10
-#define SMPLX_WP_MAX ((1 << SMPLX_WP_BITS) - 1)
+// work item (64 bits): edge index | waypoint << 32 | waypoint count << 48, so that a configuration thread needs no
+// further load to know where it sits on its edge
+#define SMPLX_WP_MAX 0xFFFF
+#define SMPLX_WORK_BLANK 0xFFFFFFFFFFFFFFFFull
 #define SMPLX_WORK_SHARDS 8
 #define SMPLX_SHARD_STRIDE 32   // ints: one 128-byte line per shard counter
 
@@ -1198,7 +1200,7 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
              const double* __restrict__ goal_dist, unsigned char* __restrict__ out_flags, double* __restrict__ out_q,
              int* __restrict__ edge_w, int* __restrict__ edge_lookups, unsigned char* __restrict__ edge_bad,
              int* __restrict__ state_lookups, unsigned char* __restrict__ state_bad,
-             unsigned int* __restrict__ work, int* __restrict__ work_count, int capacity,
+             unsigned long long* __restrict__ work, int* __restrict__ work_count, int capacity,
         const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1293,13 +1295,14 @@ k_pipe_setup(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, 
     for (int k = 0; k < wv; ++k) first += wave_sum[k];
     if (in_range) {
         if (items > 0) {
-            unsigned int* wl = work + (size_t)shard * shard_cap;
-            if (first + items <= shard_cap && W - 1 <= SMPLX_WP_MAX) {
-                for (int k = 0; k < items; ++k) wl[first + k] = ((unsigned int)tid << SMPLX_WP_BITS) | (unsigned int)(k + 1);
+            unsigned long long* wl = work + (size_t)shard * shard_cap;
+            if (first + items <= shard_cap && W <= SMPLX_WP_MAX) {
+                const unsigned long long base = (unsigned long long)tid | ((unsigned long long)W << 48);
+                for (int k = 0; k < items; ++k) wl[first + k] = base | ((unsigned long long)(k + 1) << 32);
             } else {
                 // does not fit: deferred to a fused pass (k_expand, SMPLX_F_DEFERRED); blank the part of the claim
                 // that lies below the shard's capacity
-                for (int k = first; k < first + items && k < shard_cap; ++k) wl[k] = 0xFFFFFFFFu;
+                for (int k = first; k < first + items && k < shard_cap; ++k) wl[k] = SMPLX_WORK_BLANK;
                 flags = SMPLX_F_DEFERRED;
                 atomicAdd(&work_count[SMPLX_WORK_SHARDS * SMPLX_SHARD_STRIDE], 1);
             }
@@ -1313,7 +1316,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD:
 k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
                const double* __restrict__ out_q, const int* __restrict__ edge_w, int* __restrict__ edge_lookups,
                unsigned char* __restrict__ edge_bad, int* __restrict__ state_lookups, unsigned char* __restrict__ state_bad,
-               const unsigned int* __restrict__ work, const int* __restrict__ work_count, int capacity)
+               const unsigned long long* __restrict__ work, const int* __restrict__ work_count, int capacity)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int shard_cap = capacity / SMPLX_WORK_SHARDS;
@@ -1348,12 +1351,12 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             int sh = 0;
 #pragma unroll
             for (int k = 1; k < SMPLX_WORK_SHARDS; ++k) sh += (li >= pre[k]) ? 1 : 0;
-            const unsigned int it = work[(size_t)sh * shard_cap + (li - pre[sh])];
-            if (it == 0xFFFFFFFFu) continue;
-            const long long edge = it >> SMPLX_WP_BITS;
-            const int wp = (int)(it & SMPLX_WP_MAX);
+            const unsigned long long it = work[(size_t)sh * shard_cap + (li - pre[sh])];
+            if (it == SMPLX_WORK_BLANK) continue;
+            const long long edge = (long long)(it & 0xFFFFFFFFull);
+            const int wp = (int)((it >> 32) & 0xFFFF);
+            const int W = (int)(it >> 48);
             const int si = (int)(edge / nprims);
-            const int W = edge_w[edge];
             e.start = Q + (refs ? refs[si] : (int64_t)si) * nv;
             e.finish = out_q + edge * nv;
             e.alpha = (double)wp * (1.0 / (double)(W - 1));
