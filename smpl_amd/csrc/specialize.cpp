@@ -100,8 +100,17 @@ bool compile_via_helper(const std::string& header, const std::string& dir, uint6
     std::vector<char*> argv;
     for (std::string& a : args) argv.push_back(&a[0]);
     argv.push_back(nullptr);
+    // the child only compiles: keep tool preloads of the host process (profilers, sanitizers) out of it
+    std::vector<char*> envp;
+    for (char** e = environ; e && *e; ++e) {
+        if (!strncmp(*e, "LD_PRELOAD=", 11) || !strncmp(*e, "HSA_TOOLS_LIB=", 14) || !strncmp(*e, "ROCP", 4) ||
+            !strncmp(*e, "ROCPROFILER", 11))
+            continue;
+        envp.push_back(*e);
+    }
+    envp.push_back(nullptr);
     pid_t pid = 0;
-    const int rc = posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv.data(), environ);
+    const int rc = posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv.data(), envp.data());
     bool ok = false;
     if (rc != 0) {
         why = std::string("posix_spawn: ") + strerror(rc);
