@@ -370,17 +370,13 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     if (!s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list) {
-        // a handful of states: one launch, all FK chains side by side (kernels.hip k_small_batch)
-        const int32_t* deferred = s->d_minus_one;   // "no counter": the deferred pass scans its own flags
+        // a handful of states: ONE launch, all FK chains side by side (kernels.hip k_small_batch)
         // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
         const double* qsrc = zero_copy ? zero_copy->p_q.p : d_q;
         KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
                            zero_copy ? zero_copy->p_flags.p : (unsigned char*)nullptr, zero_copy ? zero_copy->p_coord.p : (int32_t*)nullptr,
                            zero_copy ? zero_copy->p_sq.p : (double*)nullptr, zero_copy ? zero_copy->p_h.p : (int32_t*)nullptr);
-        KLAUNCH(s, K_EXPAND, k_expand, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, qsrc, norefs, B,
-                           k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups,
-                           d_counters, (const int*)deferred, stab, state_q);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (ev) (void)hipEventRecord(ev[0], stream);

@@ -1472,7 +1472,7 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 //   2 extra threads        -> the state itself (waypoint 0 of every edge) and its planning-link FK (goal distance)
 // Nothing waits for the gating: every primitive is evaluated and the goal-distance gate is applied when the lanes
 // of an edge combine (ballot over its 8 lanes), so all FK chains run concurrently.  Results are identical to the
-// pipeline.  Edges with more than 8 waypoints are deferred to k_expand like pipeline overflow.
+// pipeline.  An edge with more than 7 waypoints after the start wraps around its lanes.
 // ---------------------------------------------------------------------------------------------
 #define SMPLX_SMALL_LANES 8
 
@@ -1578,17 +1578,17 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             }
         }
     }
-    const bool too_long = W - 1 > SMPLX_SMALL_LANES - 1;
 
     // ---- lanes 0..6: one waypoint each; lane 7: the successor's bookkeeping ----
     int my_bad = 0, my_lk = 0;
     int h = 0, is_goal = 0;
-    if (edge_thread && have_action && limits_ok && !too_long) {
+    if (edge_thread && have_action && limits_ok) {
         if (slot < SMPLX_SMALL_LANES - 1) {
-            if (slot < W - 1) {
+            // waypoints slot+1, slot+8, ...: an edge longer than 7 waypoints wraps around its lanes
+            for (int wp = slot + 1; wp < W && !my_bad; wp += SMPLX_SMALL_LANES - 1) {
                 EdgeRef e;
                 e.start = parent; e.finish = sq;
-                e.alpha = (double)(slot + 1) * (1.0 / (double)(W - 1));
+                e.alpha = (double)wp * (1.0 / (double)(W - 1));
                 const bool ok = config_valid(M, L, grid, e, my_lk);
                 my_bad = ok ? 0 : 1;
             }
@@ -1627,9 +1627,6 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             flags = SMPLX_F_INACTIVE;
         } else if (!limits_ok) {
             flags = SMPLX_F_LIMITS;
-        } else if (too_long) {
-            flags = SMPLX_F_DEFERRED;
-            if (deferred_count) atomicAdd(deferred_count, 1);
         } else {
             lookups = lk + (W > 0 ? s_state_lookups : 0);
             const bool ok = (W == 0) || (s_state_bad == 0 && !edge_bad);

@@ -341,6 +341,30 @@ def test_deferred_pass_when_the_work_list_overflows(small_cfg):
         assert np.array_equal(exp["coord"][v], got["coord"][i][v]) and np.array_equal(exp["h"][v], got["h"][i][v])
 
 
+@pytest.mark.parametrize("mode", ["small", "pipeline", "generic"])
+def test_long_edges_of_25_and_more_waypoints(small_cfg, mode):
+    """Primitives of 25 and 40 cells: edges of up to ~35 waypoints.  The small-batch kernel wraps them around the 7
+    waypoint lanes of an edge, the pipeline spreads them over the work list."""
+    import copy
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = copy.copy(small_cfg)
+    cfg.mprim = scenes.mprim_text(7, [0, 1, 2, 3], [0, 1, 2, 3, 4, 5, 6], long_cells=40, short_cells=25)
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg, no_small_kernel=(mode != "small"), generic_kernels=(mode == "generic"))
+    s.fused = False
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    Q = np.vstack([np.array(cfg.start), _random_states(60, 43)])
+    got = _compare_expand(o, s, Q)
+    assert not (got["flags"] & 0x80).any()
+    A = np.repeat(Q[:8], 4, axis=0)
+    B = A.copy(); B[:, 0] += 40 * DEG
+    _, _, w = s.edge_valid_batch(A, B)
+    assert w.max() > 25
+
+
 def test_edge_cases_empty_batches_bad_start_and_goal_outside_grid(small_cfg):
     from oracle_binding import Oracle
     from smpl_amd import capi
