@@ -207,6 +207,16 @@ struct smplx_space {
     std::vector<int32_t> inflight;
     hipEvent_t batch_done = nullptr;
     bool inflight_zero_copy = false;   // the batch in flight wrote its results straight into the pinned host buffers
+    // Small batches: the single-launch kernel costs the host one launch, the pipeline several launches and copies
+    // (about 30 us more host time per batch) -- but a sparse stream of single 30 us kernels can leave the GPU at its
+    // idle clock (640 MHz seen on some boxes of the pool: 107 us per batch instead of 33 us), which the busier pipeline
+    // path does not.  Both give the same bytes, so the engine watches the issue-to-landing time of the single-launch
+    // path and sits out 2000 batches on the pipeline path whenever its average exceeds 70 us.
+    std::chrono::steady_clock::time_point t_issue;
+    bool inflight_small = false;
+    double small_latency = 0.0;   // moving average, seconds
+    int small_seen = 0, pipeline_left = 0;
+    int64_t small_launches = 0, pipe_launches = 0;
     // stats
     int64_t gpu_batches = 0, cache_hits = 0, cache_misses = 0, committed_evals = 0, gpu_evals = 0;
     // cross-query batches (smplx_plan_multi): query table + per-state query index, owned by the leading space
@@ -369,7 +379,9 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int64_t* norefs = nullptr;
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
-    if (!s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list) {
+    if (!s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list &&
+        s->pipeline_left == 0) {
+        ++s->small_launches;
         // a handful of states: ONE launch, all FK chains side by side (kernels.hip k_small_batch)
         // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
         const double* qsrc = zero_copy ? zero_copy->p_q.p : d_q;
@@ -389,6 +401,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         if (ev) (void)hipEventRecord(ev[2], stream);
     } else {
         const size_t lm = s->blob_bytes;
+        ++s->pipe_launches;
         KLAUNCH(s, K_PIPE_PREP, k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.work_count, stab, state_q);
         KLAUNCH(s, K_PIPE_SETUP, k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
@@ -494,7 +507,7 @@ bool takes_small_kernel(const smplx_space* s, int B)
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     return !s->fused_mode && s->prof_events.empty() && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
-           !s->tiny_work_list;
+           !s->tiny_work_list && s->pipeline_left == 0;
 }
 
 // enqueue one frontier batch (state `id` plus hinted frontier states) on the space's stream: upload, the
@@ -515,7 +528,10 @@ int issue_batch(smplx_space* s, int id)
     if ((e = s->p_sq.reserve(BM * N))) return e;
     if ((e = s->p_h.reserve(BM))) return e;
     for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
+    if (s->pipeline_left > 0 && B <= s->small_batch_max) --s->pipeline_left;   // sitting out on the pipeline path (see smplx_space)
     s->inflight_zero_copy = takes_small_kernel(s, B);
+    s->inflight_small = s->inflight_zero_copy;
+    s->t_issue = std::chrono::steady_clock::now();
     if (s->inflight_zero_copy) {
         if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
                                s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, s))) return e;
@@ -542,6 +558,13 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
     const int N = s->N, M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
+    if (src == s && s->inflight_small) {
+        // issue-to-landing time of the single-launch path (the search thread has been polling since the issue)
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_issue).count();
+        s->small_latency = s->small_seen == 0 ? dt : 0.8 * s->small_latency + 0.2 * dt;
+        if (++s->small_seen >= 16 && s->small_latency > 70e-6) { s->pipeline_left = 2000; s->small_seen = 0; }
+        s->inflight_small = false;
+    }
     if (src == s && s->inflight_zero_copy) {
         // edges too long for the single-launch kernel were finished by the deferred pass in device memory only:
         // fetch the device copies in that (rare) case
@@ -1610,7 +1633,8 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
                 t_wait += secs(w0, now());
             }
         }
-        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs\n", t_resume, t_wait, t_collect);
+        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs; launches: single-kernel %lld pipeline %lld\n",
+                         t_resume, t_wait, t_collect, (long long)spaces[0]->small_launches, (long long)spaces[0]->pipe_launches);
     }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (wall_seconds) *wall_seconds = wall;
