@@ -136,6 +136,28 @@ struct CoordTable {
     }
 };
 
+// Dense outputs of a planner frontier batch in ONE allocation -- successor joint values | coordinates | heuristic |
+// flags -- so that they come back in one DMA copy; the device block and its pinned host twin share the layout.
+struct OutView {
+    double* sq = nullptr;
+    int32_t* coord = nullptr;
+    int32_t* h = nullptr;
+    unsigned char* flags = nullptr;
+    size_t bytes = 0;
+};
+
+inline OutView carve_out(unsigned char* base, size_t BM, int N)
+{
+    OutView v;
+    size_t o = 0;
+    v.sq = (double*)(base + o); o += BM * N * sizeof(double);
+    v.coord = (int32_t*)(base + o); o += BM * N * sizeof(int32_t);
+    v.h = (int32_t*)(base + o); o += BM * sizeof(int32_t);
+    v.flags = base + o; o += BM;
+    v.bytes = (o + 15) / 16 * 16;
+    return v;
+}
+
 }  // namespace
 
 struct smplx_grid {
@@ -182,9 +204,10 @@ struct smplx_space {
     bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
     int small_batch_max = 256;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
     DevBuf<unsigned long long> b_counters;
-    PinBuf<double> p_q, p_sq;
-    PinBuf<unsigned char> p_flags;
-    PinBuf<int32_t> p_coord, p_h, p_lookups;
+    PinBuf<double> p_q;
+    DevBuf<unsigned char> b_out;   // packed outputs of a planner batch (OutView)
+    PinBuf<unsigned char> p_out;
+    OutView dv, pv;                // views of the batch in flight: device block, pinned host twin
     // lattice: commit-ordered state table (manip_lattice.cpp:1302-1354)
     std::vector<int32_t> coords;
     std::vector<double> qs;
@@ -387,8 +410,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         const double* qsrc = zero_copy ? zero_copy->p_q.p : d_q;
         KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
-                           zero_copy ? zero_copy->p_flags.p : (unsigned char*)nullptr, zero_copy ? zero_copy->p_coord.p : (int32_t*)nullptr,
-                           zero_copy ? zero_copy->p_sq.p : (double*)nullptr, zero_copy ? zero_copy->p_h.p : (int32_t*)nullptr);
+                           zero_copy ? zero_copy->pv.flags : (unsigned char*)nullptr, zero_copy ? zero_copy->pv.coord : (int32_t*)nullptr,
+                           zero_copy ? zero_copy->pv.sq : (double*)nullptr, zero_copy ? zero_copy->pv.h : (int32_t*)nullptr);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (ev) (void)hipEventRecord(ev[0], stream);
@@ -523,29 +546,27 @@ int issue_batch(smplx_space* s, int id)
     if (int e = reserve_expand(s, B)) return e;
     int e;
     if ((e = s->p_q.reserve((size_t)B * N))) return e;
-    if ((e = s->p_flags.reserve(BM))) return e;
-    if ((e = s->p_coord.reserve(BM * N))) return e;
-    if ((e = s->p_sq.reserve(BM * N))) return e;
-    if ((e = s->p_h.reserve(BM))) return e;
+    const size_t out_bytes = carve_out(nullptr, BM, N).bytes;
+    if ((e = s->b_out.reserve(out_bytes))) return e;
+    if ((e = s->p_out.reserve(out_bytes))) return e;
+    s->dv = carve_out(s->b_out.p, BM, N);
+    s->pv = carve_out(s->p_out.p, BM, N);
     for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
     if (s->pipeline_left > 0 && B <= s->small_batch_max) --s->pipeline_left;   // sitting out on the pipeline path (see smplx_space)
     s->inflight_zero_copy = takes_small_kernel(s, B);
     s->inflight_small = s->inflight_zero_copy;
     s->t_issue = std::chrono::steady_clock::now();
     if (s->inflight_zero_copy) {
-        if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
+        if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
                                s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, s))) return e;
         HIP_TRY(hipEventRecord(s->batch_done, s->stream));
         ++s->gpu_batches;
         return SMPLX_OK;
     }
     HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * B * N, hipMemcpyHostToDevice, s->stream));
-    if ((e = launch_expand(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
+    if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
                            s->b_work.p, s->b_counters.p, s->stream))) return e;
-    HIP_TRY(hipMemcpyAsync(s->p_flags.p, s->b_flags.p, BM, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->p_h.p, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->p_coord.p, s->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->p_sq.p, s->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->p_out.p, s->b_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));   // one copy for all four outputs
     HIP_TRY(hipEventRecord(s->batch_done, s->stream));
     ++s->gpu_batches;
     return SMPLX_OK;
@@ -565,36 +586,23 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         if (++s->small_seen >= 16 && s->small_latency > 70e-6) { s->pipeline_left = 2000; s->small_seen = 0; }
         s->inflight_small = false;
     }
-    if (src == s && s->inflight_zero_copy) {
-        // edges too long for the single-launch kernel were finished by the deferred pass in device memory only:
-        // fetch the device copies in that (rare) case
-        const size_t BM = (size_t)B * M;
-        bool deferred = false;
-        for (size_t k = 0; k < BM && !deferred; ++k) deferred = (s->p_flags.p[k] & SMPLX_F_DEFERRED) != 0;
-        if (deferred) {
-            HIP_TRY(hipMemcpy(s->p_flags.p, s->b_flags.p, BM, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(s->p_h.p, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(s->p_coord.p, s->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(s->p_sq.p, s->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost));
-        }
-        s->inflight_zero_copy = false;
-    }
+    if (src == s) s->inflight_zero_copy = false;
     for (int i = 0; i < B; ++i) {
         const int sid = batch[i];
         s->cache_off[sid] = (int64_t)s->recs.size();
         int cnt = 0, evals = 0;
         for (int p = 0; p < M; ++p) {
             const size_t k = (first + (size_t)i) * M + p;
-            const unsigned char f = src->p_flags.p[k];
+            const unsigned char f = src->pv.flags[k];
             if (!(f & SMPLX_F_INACTIVE)) ++evals;
             if (!(f & SMPLX_F_VALID)) continue;
             smplx_space::Rec r;
             r.cost = s->actions.dev.cost[p];
-            r.h = src->p_h.p[k];
+            r.h = src->pv.h[k];
             r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
             s->recs.push_back(r);
-            s->rec_coord.insert(s->rec_coord.end(), &src->p_coord.p[k * N], &src->p_coord.p[k * N] + N);
-            s->rec_q.insert(s->rec_q.end(), &src->p_sq.p[k * N], &src->p_sq.p[k * N] + N);
+            s->rec_coord.insert(s->rec_coord.end(), &src->pv.coord[k * N], &src->pv.coord[k * N] + N);
+            s->rec_q.insert(s->rec_q.end(), &src->pv.sq[k * N], &src->pv.sq[k * N] + N);
             ++cnt;
         }
         s->cache_cnt[sid] = cnt;
@@ -1495,10 +1503,11 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
             if ((e = lead->b_stateq.reserve(total))) return e;
             if ((e = lead->p_stateq.reserve(total))) return e;
             if ((e = lead->p_q.reserve(total * N))) return e;
-            if ((e = lead->p_flags.reserve(BM))) return e;
-            if ((e = lead->p_coord.reserve(BM * N))) return e;
-            if ((e = lead->p_sq.reserve(BM * N))) return e;
-            if ((e = lead->p_h.reserve(BM))) return e;
+            const size_t out_bytes = carve_out(nullptr, BM, N).bytes;
+            if ((e = lead->b_out.reserve(out_bytes))) return e;
+            if ((e = lead->p_out.reserve(out_bytes))) return e;
+            lead->dv = carve_out(lead->b_out.p, BM, N);
+            lead->pv = carve_out(lead->p_out.p, BM, N);
             size_t row = 0;
             for (int q : reqs) {
                 const smplx_space* sq = spaces[q];
@@ -1510,12 +1519,9 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
             }
             HIP_TRY(hipMemcpyAsync(lead->b_q.p, lead->p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, lead->stream));
             HIP_TRY(hipMemcpyAsync(lead->b_stateq.p, lead->p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, lead->stream));
-            if ((e = launch_expand(lead, lead->b_q.p, B, lead->b_flags.p, lead->b_coord.p, lead->b_sq.p, lead->b_h.p, lead->b_cost.p,
+            if ((e = launch_expand(lead, lead->b_q.p, B, lead->dv.flags, lead->dv.coord, lead->dv.sq, lead->dv.h, lead->b_cost.p,
                                    lead->b_lookups.p, lead->b_work.p, nullptr, lead->stream, lead->b_stab.p, lead->b_stateq.p))) return e;
-            HIP_TRY(hipMemcpyAsync(lead->p_flags.p, lead->b_flags.p, BM, hipMemcpyDeviceToHost, lead->stream));
-            HIP_TRY(hipMemcpyAsync(lead->p_h.p, lead->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, lead->stream));
-            HIP_TRY(hipMemcpyAsync(lead->p_coord.p, lead->b_coord.p, sizeof(int32_t) * BM * N, hipMemcpyDeviceToHost, lead->stream));
-            HIP_TRY(hipMemcpyAsync(lead->p_sq.p, lead->b_sq.p, sizeof(double) * BM * N, hipMemcpyDeviceToHost, lead->stream));
+            HIP_TRY(hipMemcpyAsync(lead->p_out.p, lead->b_out.p, out_bytes, hipMemcpyDeviceToHost, lead->stream));
             HIP_TRY(hipStreamSynchronize(lead->stream));
             ++lead->gpu_batches;
             row = 0;
