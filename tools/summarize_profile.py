@@ -15,10 +15,18 @@ def find(out, stem, kind):
 
 
 def kernel_trace(path):
+    """Durations per kernel.  The bench builds its frontier with a real search first, which launches the same kernels
+    on small batches: for the kernels of the timed step only the launches with the largest grid (the B=4096 step) count."""
+    rows = list(csv.DictReader(open(path)))
+    big = defaultdict(int)
+    for r in rows:
+        big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size_X"]))
     per = defaultdict(list)
     meta = {}
-    for r in csv.DictReader(open(path)):
+    for r in rows:
         n = r["Kernel_Name"]
+        if n in STEP_KERNELS and int(r["Grid_Size_X"]) != big[n]:
+            continue
         per[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[n] = {"grid_threads": int(r["Grid_Size_X"]), "block": int(r["Workgroup_Size_X"]), "vgpr": int(r["VGPR_Count"]),
                    "sgpr": int(r["SGPR_Count"]), "lds_bytes": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"])}
@@ -29,7 +37,13 @@ def counters(path):
     acc = defaultdict(lambda: defaultdict(list))
     if not path:
         return acc
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    big = defaultdict(int)
+    for r in rows:
+        big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
+    for r in rows:
+        if int(r["Grid_Size"]) != big[r["Kernel_Name"]]:
+            continue   # launches on small batches while the bench builds its frontier
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
