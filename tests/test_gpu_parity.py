@@ -30,7 +30,9 @@ def ctx(small_cfg, request):
                                no_small_kernel=(request.param in ("pipeline", "generic")),
                                generic_kernels=(request.param == "generic"))
     ok, note = s.specialized()
-    assert ok == (request.param != "generic"), "per-robot kernel build: " + note
+    if request.param == "generic":
+        assert not ok
+    # (that the per-robot build is actually in use is asserted once, in tests/test_zz_per_robot_build.py)
     s.fused = request.param == "fused"
     o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
     s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)

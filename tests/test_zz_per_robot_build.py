@@ -1,0 +1,19 @@
+"""Runs last: the per-robot kernel build (smpl_amd/csrc/specialize.cpp) must be what the GPU box actually ran.
+The parity tests before this one hold for either build; a silent fall-back to the generic kernels would only show as
+lost speed, so it is made loud here."""
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_per_robot_build_is_active_and_came_from_the_helper(small_cfg):
+    from smpl_amd import capi
+    if os.environ.get("SMPLX_SPECIALIZE", "") == "0":
+        pytest.skip("per-robot build disabled by SMPLX_SPECIALIZE=0")
+    s = capi.Space.from_config(small_cfg)
+    ok, note = s.specialized()
+    assert ok, "generic kernels in use: " + note
+    # "compiled by smplx_rtc" or "disk cache" (a code object smplx_rtc left there); "in-process" means the helper is missing
+    assert "in-process" not in note, note
