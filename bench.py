@@ -61,8 +61,8 @@ def aggregate(allrec):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--multi-queries", type=int, default=32, help="queries interleaved on one GPU in the planner leg")
     ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the planner_multi leg")
     ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
+    ap.add_argument("--profile-steps", type=int, default=0,
+                    help="timed steps whose kernels are bracketed by HIP events (default: steps/8, at least 1); every "
+                         "event costs the stream a marker, about 3 us, three of them per profiled step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--generic-kernels", action="store_true", help="skip the per-robot hiprtc build (A/B runs)")
@@ -134,7 +137,7 @@ def main():
         step()
     torch.cuda.synchronize()
     d_cnt.zero_()
-    space.profile_begin(args.steps)
+    space.profile_begin(min(args.steps, args.profile_steps if args.profile_steps > 0 else max(1, args.steps // 8)))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -157,11 +160,12 @@ def main():
     # ---- roofline of the dominant kernel (k_pipe_configs: the collision check), this rank ----
     # SURVEY 8(d), collision kernel: algorithmic bytes = 4 B per distance-grid lookup + 8N B per configuration.
     # HIP events on the launch stream bracket the kernel inside the timed region (smplx_profile_*).
-    L_ = max(launches, 1)
+    L_ = max(args.steps, 1)        # the tallies cover every timed step
+    P_ = max(launches, 1)          # the events cover the first --profile-steps of them
     cfg_per_launch = configs / L_
     lk_per_launch = (lookups_done + state_lookups) / L_
     alg_bytes = 4.0 * lk_per_launch + 8.0 * N * cfg_per_launch
-    k_ms = prep_ms / L_            # first event interval = k_pipe_configs
+    k_ms = prep_ms / P_            # first event interval = k_pipe_configs
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     # HBM-side bytes of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     # runs; gfx950 correction applied) -- kept in profiles/traffic.json, null when that file is absent
@@ -173,7 +177,7 @@ def main():
         traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "kernel": "k_pipe_configs",
-                "kernel_ms": round(k_ms, 4), "finish_kernel_ms": round(expand_ms / L_, 4),
+                "kernel_ms": round(k_ms, 4), "finish_kernel_ms": round(expand_ms / P_, 4), "profiled_steps": int(launches),
                 "algorithmic_bytes_per_launch": int(alg_bytes), "configs_per_launch": int(cfg_per_launch),
                 "lookups_per_launch": int(lk_per_launch), "evals_per_launch": int(evals / L_),
                 "succ_eval_bytes_per_launch": int(evals / L_ * (20 * N + 8) + 4.0 * lookups_ref / L_),
@@ -219,7 +223,7 @@ def main():
         torch.cuda.synchronize()
         t1o = time.perf_counter()
         out["overlapped"] = {"streams": S_, "steps": nst, "ms_per_step": round(1e3 * (t1o - t0o) / nst, 4),
-                             "successor_evaluations_per_s": round(evals / max(launches, 1) * nst / (t1o - t0o), 1)}
+                             "successor_evaluations_per_s": round(evals / max(args.steps, 1) * nst / (t1o - t0o), 1)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
