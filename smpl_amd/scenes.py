@@ -137,6 +137,69 @@ def dual_arm14_robot() -> str:
     return t
 
 
+MIXED_LIMITS = [(-1.5, 1.5), (0.0, 0.25), (-1.2, 1.2), (-math.pi, math.pi), (-1.0, 1.0)]
+MIXED_START = [0.1, 0.05, -0.2, 0.3, 0.2]
+
+
+def mixed_kinds_robot() -> str:
+    """A 5-variable test robot that takes every branch of the joint-transform functions
+    (sbpl_collision_checking/src/transform_functions.h:95-258): origins with a rotation (general forms), a revolute
+    joint about an axis that is none of X/Y/Z (origin * AngleAxis), a prismatic joint (moves along its LOCAL Z whatever
+    the axis says), a continuous joint, identity-origin joints, and a fixed joint with a rotated origin."""
+    L = ["robot mixed_kinds", "link base_link"]
+    for n in ["pedestal", "turret", "mast", "boom", "roll_link", "wrist", "pad", "tool_link"]:
+        L.append(f"link {n}")
+    J = "joint {n} {t} {pa} {ch}  {o[0]} {o[1]} {o[2]}  {r[0]} {r[1]} {r[2]}  {a[0]} {a[1]} {a[2]}  {lo} {hi}"
+
+    def joint(n, t, pa, ch, o=(0, 0, 0), r=(0, 0, 0), a=(0, 0, 1), lo=0.0, hi=0.0):
+        L.append(J.format(n=n, t=t, pa=pa, ch=ch, o=o, r=r, a=a, lo=lo, hi=hi))
+
+    joint("mount", "fixed", "base_link", "pedestal", o=(0.05, -0.15, 0.55), r=(0.0, 0.0, 0.3))
+    joint("pan", "revolute", "pedestal", "turret", o=(0.0, 0.0, 0.10), r=(0.1, 0.2, 0.3), a=(0, 0, 1), lo=-1.5, hi=1.5)
+    joint("lift", "prismatic", "turret", "mast", o=(0.05, 0.0, 0.05), r=(0.0, 0.4, 0.0), a=(1, 0, 0), lo=0.0, hi=0.25)
+    joint("swing", "revolute", "mast", "boom", o=(0.0, 0.0, 0.20), a=(0.6, 0.0, 0.8), lo=-1.2, hi=1.2)
+    joint("roll", "continuous", "boom", "roll_link", o=(0.25, 0.0, 0.0), r=(0.0, -0.3, 0.2), a=(1, 0, 0))
+    joint("flex", "revolute", "roll_link", "wrist", o=(0.20, 0.0, 0.0), a=(0, 1, 0), lo=-1.0, hi=1.0)
+    joint("pad_mount", "fixed", "wrist", "pad", o=(0.08, 0.0, 0.0), r=(0.5, 0.0, 0.0))
+    joint("tool", "fixed", "wrist", "tool_link", o=(0.15, 0.0, 0.0))
+
+    def sph(link, name, x, y, z, r, pr=1):
+        L.append(f"sphere {link} {name} {x} {y} {z} {r} {pr}")
+
+    sph("turret", "tu0", 0.0, 0.0, 0.05, 0.10, 3)
+    sph("mast", "ma0", 0.0, 0.0, 0.08, 0.07, 3)
+    sph("mast", "ma1", 0.0, 0.0, 0.18, 0.06, 3)
+    sph("boom", "bo0", 0.08, 0.0, 0.0, 0.07, 2)
+    sph("boom", "bo1", 0.18, 0.0, 0.0, 0.06, 2)
+    sph("roll_link", "ro0", 0.07, 0.0, 0.0, 0.06, 2)
+    sph("roll_link", "ro1", 0.15, 0.01, 0.0, 0.05, 2)
+    sph("wrist", "wr0", 0.05, 0.0, 0.0, 0.05, 1)
+    sph("pad", "pa0", 0.03, 0.02, 0.0, 0.035, 1)
+    sph("pad", "pa1", 0.03, -0.02, 0.0, 0.035, 1)
+    t = "\n".join(L) + "\n"
+    t += "group arm turret mast boom roll_link wrist pad\n"
+    t += "acm mast roll_link\nacm boom wrist\nacm roll_link pad\n"
+    t += "planning_joints pan lift swing roll flex\n"
+    t += "planning_link tool_link\n"
+    return t
+
+
+def config_mixed(n: int = 64, seed: int = 11, nboxes: int = 5) -> "Config":
+    """The mixed-kinds robot in a small cluttered scene; the prismatic variable is discretised in metres."""
+    res = 0.04
+    size = n * res
+    origin = (0.4 - 0.5 * size, -0.5 * size, 0.8 - 0.5 * size)
+    rng = np.random.default_rng(seed)
+    clear = [(0.05, -0.15, 0.6), (0.1, -0.15, 0.9), (0.3, -0.1, 1.0), (0.5, 0.0, 1.0)]
+    boxes = [TABLETOP] + random_boxes(rng, nboxes, origin, (n, n, n), res, clear, 0.30)
+    grid = build_grid(origin, (n, n, n), res, 0.4, boxes)
+    p = PlanningParams([2 * DEG, 0.01, 2 * DEG, 2 * DEG, 2 * DEG], eps0=5.0, bfs_radius=0.04, cost_per_cell=500)
+    goal = [MIXED_START[0] + 20 * 2 * DEG, MIXED_START[1] + 8 * 0.01, MIXED_START[2] - 12 * 2 * DEG,
+            MIXED_START[3] + 8 * 2 * DEG, MIXED_START[4] - 8 * 2 * DEG]
+    return Config("mixed", mixed_kinds_robot(), mprim_text(5, range(3), range(5), long_cells=4, short_cells=2), grid, p,
+                  list(MIXED_START), goal, [3.0 * DEG, 0.02, 3.0 * DEG, 3.0 * DEG, 3.0 * DEG], boxes)
+
+
 def mprim_text(nvars: int, long_joints, short_joints, long_cells: int = 7, short_cells: int = 4) -> str:
     """Upstream .mprim layout (smpl_test/config/pr2.mprim has 4 long rows of 7 and 7 short rows of 4)."""
     rows = []

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.SYMBOLS) == declared   # the Python binding knows exactly the header's entry points
 
 
-@pytest.mark.parametrize("robot", [scenes.arm7_robot, scenes.dual_arm14_robot])
+@pytest.mark.parametrize("robot", [scenes.arm7_robot, scenes.dual_arm14_robot, scenes.mixed_kinds_robot])
 def test_host_model_compiler_matches_oracle_bitwise(robot, small_cfg):
     import copy
     cfg = copy.copy(small_cfg)
@@ -32,6 +32,9 @@ def test_host_model_compiler_matches_oracle_bitwise(robot, small_cfg):
     if robot is scenes.dual_arm14_robot:
         cfg.params = scenes.PlanningParams([scenes.DEG] * 14)
         cfg.mprim = scenes.mprim_text(14, range(14), range(14))
+    if robot is scenes.mixed_kinds_robot:   # rotated origins, a generic axis, a prismatic and a continuous joint
+        cfg.params = scenes.PlanningParams([2 * scenes.DEG, 0.01, 2 * scenes.DEG, 2 * scenes.DEG, 2 * scenes.DEG])
+        cfg.mprim = scenes.mprim_text(5, range(3), range(5))
     om = Oracle(cfg).model()
     m = capi.Model(cfg.robot_text)
     pm = m.arrays()
@@ -52,8 +55,10 @@ def test_host_model_compiler_matches_oracle_bitwise(robot, small_cfg):
         assert (m.njoints, m.nvars, m.ntrees, m.nnodes, m.npairs, m.nslots) == (13, 7, 8, 38, 11, 1)
         leaves = int((pm["left"] < 0).sum())
         assert leaves == 23                                       # trees of 1,4,7,3,2,2,2,2 leaves
-    else:
+    elif robot is scenes.dual_arm14_robot:
         assert m.nvars == 14 and m.ntrees == 16 and int((pm["left"] < 0).sum()) == 46
+    else:
+        assert m.nvars == 5 and m.ntrees == 6 and int((pm["left"] < 0).sum()) == 10
 
 
 def test_parse_errors_and_limits_map_to_codes():
@@ -125,12 +130,12 @@ def test_model_constants_header_describes_the_chain(small_cfg):
     assert "0x1." in h.split("CM_VAR_K")[1].split("\n")[0]
 
 
-@pytest.mark.parametrize("robot", ["arm7", "dual14"])
+@pytest.mark.parametrize("robot", ["arm7", "dual14", "mixed"])
 def test_per_robot_source_compiles_for_gfx950_with_the_helper(robot, tmp_path):
     """What smplx_space_create does on the GPU box, minus the module load: header -> smplx_rtc -> code object."""
     import subprocess
     from smpl_amd import build, scenes
-    text = scenes.arm7_robot() if robot == "arm7" else scenes.dual_arm14_robot()
+    text = {"arm7": scenes.arm7_robot, "dual14": scenes.dual_arm14_robot, "mixed": scenes.mixed_kinds_robot}[robot]()
     hp, op = tmp_path / "model_const.h", tmp_path / "k.hsaco"
     hp.write_text(_const_header(text))
     subprocess.check_call([build.RTC, str(hp), str(op)], timeout=600)

@@ -243,6 +243,51 @@ def test_post_process_path_equals_reference_loops(ctx, planned_path, mode):
         assert np.array_equal(got, paths[-1])
 
 
+@pytest.fixture(scope="module", params=["per-robot", "generic", "per-robot-pipeline", "fused"])
+def mixed_ctx(request):
+    """The robot that takes every branch of the joint-transform functions (rotated origins, generic axis, prismatic,
+    continuous): its per-robot build keeps the joint records in LDS for the kinds without a literal form."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = scenes.config_mixed()
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg, generic_kernels=(request.param == "generic"), fused=(request.param == "fused"),
+                               no_small_kernel=(request.param == "per-robot-pipeline"))
+    s.fused = request.param == "fused"
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    return cfg, o, s
+
+
+def test_mixed_joint_kinds_positions_validity_and_expansion(mixed_ctx):
+    cfg, o, s = mixed_ctx
+    Q = np.vstack([np.array(cfg.start), np.array(cfg.goal), scenes.random_states(scenes.MIXED_LIMITS, 120, 9)])
+    nn = o.model()["xyzr"].shape[0]
+    pos = s.sphere_positions(Q)
+    for i, q in enumerate(Q[:40]):
+        assert np.array_equal(pos[i], o.sphere_positions(q, nn))      # every transform kind, bit for bit
+    ok, lk = s.state_valid_batch(Q)
+    for i, q in enumerate(Q):
+        eo, el = o.state_valid(q)
+        assert bool(ok[i]) == eo
+        if eo:
+            assert lk[i] == el
+    V = Q[ok.astype(bool)][:48]
+    _compare_expand(o, s, V)
+
+
+def test_mixed_joint_kinds_search(mixed_ctx):
+    cfg, o, s = mixed_ctx
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    o.search_params(5.0, 1.0, 1.0, True, True, 3000, 3000)
+    eo = o.plan()
+    go = s.plan(5.0, 1.0, 1.0, True, True, 3000, 3000)
+    assert eo["ok"] == go["solved"] and eo["cost"] == go["cost"]
+    assert np.array_equal(eo["expansion_log"], go["expansion_log"])
+    assert np.array_equal(eo["path"], go["path"])
+
+
 @pytest.fixture(scope="module")
 def dual_ctx():
     """14-DOF dual arm (SURVEY cfg 5 robot) on a coarse grid: two kinematic chains from the root, 16 sphere trees,
