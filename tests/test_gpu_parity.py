@@ -388,6 +388,43 @@ def test_deferred_pass_when_the_work_list_overflows(small_cfg):
         assert np.array_equal(exp["coord"][v], got["coord"][i][v]) and np.array_equal(exp["h"][v], got["h"][i][v])
 
 
+@pytest.mark.parametrize("long_and_short", [False, True])
+def test_fork_mprim_rows_with_weights_and_long_and_short_gating(small_cfg, long_and_short):
+    """[FORK] .mprim rows carry a group and a weight after the deltas (manip_lattice_action_space.cpp:149,161-186):
+    the weight scales the edge cost (manip_lattice.cpp:1414-1437); use_long_and_short keeps both families active
+    (:662-691)."""
+    import copy
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = copy.copy(small_cfg)
+    rows = []
+    for j, (cells, w) in enumerate([(7, 1.0), (7, 2.5), (6, 0.5), (5, 1.25)]):
+        r = [0] * 7; r[j] = cells
+        rows.append(" ".join(map(str, r)) + f" {j % 2} {w}")
+    for j, w in enumerate([1.0, 0.75, 3.0, 1.0, 0.2, 1.0, 1.5]):
+        r = [0] * 7; r[j] = 3
+        rows.append(" ".join(map(str, r)) + f" 1 {w}")
+    cfg.mprim = "Motion_Primitives(degrees): 11 9 7\n" + "\n".join(rows) + "\n"
+    cfg.params = copy.copy(cfg.params)
+    cfg.params.use_long_and_short = long_and_short
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg)
+    s.fused = False
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    near = np.array(cfg.goal) + np.array([2, -1, 1, 0, 3, -2, 1]) * DEG
+    Q = np.vstack([np.array(cfg.start), near, _random_states(60, 47)])
+    got = _compare_expand(o, s, Q)
+    costs = set(np.unique(got["cost"][(got["flags"] & 1) != 0]).tolist())
+    assert {2500, 500, 1250, 750, 3000, 200} & costs           # weighted costs show up: int(1000 * weight)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    o.search_params(5.0, 1.0, 1.0, True, True, 2500, 2500)
+    eo = o.plan()
+    go = s.plan(5.0, 1.0, 1.0, True, True, 2500, 2500)
+    assert eo["cost"] == go["cost"] and np.array_equal(eo["expansion_log"], go["expansion_log"])
+
+
 @pytest.mark.parametrize("mode", ["small", "pipeline", "generic"])
 def test_long_edges_of_25_and_more_waypoints(small_cfg, mode):
     """Primitives of 25 and 40 cells: edges of up to ~35 waypoints.  The small-batch kernel wraps them around the 7
