@@ -84,6 +84,7 @@ void orc_destroy(void* h) { delete (Ctx*)h; }
 int orc_num_vars(void* h) { return ((Ctx*)h)->robot.jointVariableCount(); }
 int orc_num_prims(void* h) { return (int)((Ctx*)h)->actions.mprims.size(); }
 void orc_set_traversal_order(void* h, int order) { ((Ctx*)h)->cc->order = (TraversalOrder)order; }
+void orc_set_padding(void* h, double padding) { ((Ctx*)h)->cc->padding = padding; }   // SelfCollisionModel m_padding
 
 // --- compiled-model inspection (compared bit for bit with the product's host compiler) ---
 int orc_model_counts(void* h, int* njoints, int* ntrees, int* nnodes, int* npairs)

@@ -163,7 +163,8 @@ class Space:
     """ManipLattice + BfsHeuristic + CollisionSpace for one query, on one GPU."""
 
     def __init__(self, model: Model, grid: Grid, mprim_text: str, params, batch_states: int = 0, fused: bool = False,
-                 tiny_work_list: bool = False, no_small_kernel: bool = False, generic_kernels: bool = False):
+                 tiny_work_list: bool = False, no_small_kernel: bool = False, generic_kernels: bool = False,
+                 padding: float = 0.0):
         self.model, self.grid = model, grid
         P = Params()
         for i, r in enumerate(params.resolutions):
@@ -176,7 +177,7 @@ class Space:
         P.xyzrpy_snap_dist_thresh = params.xyzrpy_thresh
         P.xy_rotate_by_var3 = int(params.xy_rotate_by_var3)
         P.use_long_and_short = int(params.use_long_and_short)
-        P.padding = 0.0
+        P.padding = padding
         P.batch_states = batch_states
         P.reserved = ((1 if fused else 0) | (2 if tiny_work_list else 0) | (4 if no_small_kernel else 0) |
                       (8 if generic_kernels else 0))
@@ -187,7 +188,7 @@ class Space:
 
     @classmethod
     def from_config(cls, cfg, batch_states: int = 0, xy_rotate=None, fused: bool = False, tiny_work_list: bool = False,
-                    no_small_kernel: bool = False, generic_kernels: bool = False):
+                    no_small_kernel: bool = False, generic_kernels: bool = False, padding: float = 0.0):
         g = Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
         m = Model(cfg.robot_text)
         p = cfg.params
@@ -195,7 +196,7 @@ class Space:
             import copy
             p = copy.copy(p)
             p.xy_rotate_by_var3 = xy_rotate
-        return cls(m, g, cfg.mprim, p, batch_states, fused, tiny_work_list, no_small_kernel, generic_kernels)
+        return cls(m, g, cfg.mprim, p, batch_states, fused, tiny_work_list, no_small_kernel, generic_kernels, padding)
 
     def specialized(self):
         """(True/False, note): whether the space runs the per-robot kernel build (smplx_space_specialized)."""

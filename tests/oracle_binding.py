@@ -94,6 +94,10 @@ class Oracle:
         return dict(origins=origins, k=k, xyzr=xyzr, left=left, right=right, link=link, tree_first=first,
                     pairs=pairs, coord_vals=vals, coord_deltas=deltas)
 
+    def set_padding(self, padding: float):
+        self.lib.orc_set_padding.argtypes = [C.c_void_p, C.c_double]
+        self.lib.orc_set_padding(self.h, padding)
+
     def set_order(self, chain: bool):
         self.lib.orc_set_traversal_order(self.h, 1 if chain else 0)
 

@@ -388,6 +388,28 @@ def test_deferred_pass_when_the_work_list_overflows(small_cfg):
         assert np.array_equal(exp["coord"][v], got["coord"][i][v]) and np.array_equal(exp["h"][v], got["h"][i][v])
 
 
+@pytest.mark.parametrize("padding", [0.013, 0.05])
+def test_sphere_padding(small_cfg, padding):
+    """SelfCollisionModel's m_padding (collision_operations.h:67-77: valid iff dist^2 >= (r + pad)^2): the engine folds
+    it into the integer thresholds (model_compile.cpp sphere_threshold)."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    o = Oracle(small_cfg)
+    o.set_order(chain=True)
+    o.set_padding(padding)
+    s = capi.Space.from_config(small_cfg, padding=padding)
+    s.fused = False
+    o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    Q = _random_states(300, 53)
+    ok, lk = s.state_valid_batch(Q)
+    exp = [o.state_valid(q) for q in Q]
+    assert np.array_equal(ok.astype(bool), np.array([e[0] for e in exp]))
+    ok0, _ = capi.Space.from_config(small_cfg).state_valid_batch(Q)
+    assert ok.sum() < ok0.sum()                     # the padding does reject states the bare spheres accept
+    _compare_expand(o, s, Q[ok.astype(bool)][:40])
+
+
 @pytest.mark.parametrize("long_and_short", [False, True])
 def test_fork_mprim_rows_with_weights_and_long_and_short_gating(small_cfg, long_and_short):
     """[FORK] .mprim rows carry a group and a weight after the deltas (manip_lattice_action_space.cpp:149,161-186):
