@@ -388,6 +388,27 @@ def test_deferred_pass_when_the_work_list_overflows(small_cfg):
         assert np.array_equal(exp["coord"][v], got["coord"][i][v]) and np.array_equal(exp["h"][v], got["h"][i][v])
 
 
+def test_distance_cap_below_the_sphere_radii(small_cfg):
+    """A distance field capped at 0.12 m (3 cells) against spheres of up to 0.15 m: the cap makes a big sphere
+    "collide" wherever it is (distance_map.hpp:281-300 caps at dmax; collision_operations.h:67-77), so the traversal
+    always descends and a big LEAF always fails.  Thresholds beyond the cap take the dmax^2 + 1 sentinel."""
+    import copy
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = copy.copy(small_cfg)
+    g = small_cfg.grid
+    cfg.grid = scenes.build_grid(g.origin, g.dims, g.res, 0.12, small_cfg.boxes)
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg, fused=True)
+    Q = _random_states(100, 59)
+    ok, lk = s.state_valid_batch(Q)
+    for i, q in enumerate(Q):
+        eo, el = o.state_valid(q)
+        assert bool(ok[i]) == eo and lk[i] == el     # one thread per state: the reference's early exit, tally for tally
+    assert not ok.any()                              # the 0.15 m shoulder leaf can never clear a 0.12 m cap
+
+
 @pytest.mark.parametrize("padding", [0.013, 0.05])
 def test_sphere_padding(small_cfg, padding):
     """SelfCollisionModel's m_padding (collision_operations.h:67-77: valid iff dist^2 >= (r + pad)^2): the engine folds
