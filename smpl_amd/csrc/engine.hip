@@ -237,6 +237,7 @@ struct smplx_space {
     // path and sits out 2000 batches on the pipeline path whenever its average exceeds 70 us.
     std::chrono::steady_clock::time_point t_issue;
     bool inflight_small = false;
+    bool adaptive_small = false;  // only a lone query measures: with several queries per thread the landing time includes their turns
     double small_latency = 0.0;   // moving average, seconds
     int small_seen = 0, pipeline_left = 0;
     int64_t small_launches = 0, pipe_launches = 0;
@@ -579,14 +580,13 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
     const int N = s->N, M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
-    if (src == s && s->inflight_small) {
+    if (src == s && s->inflight_small && s->adaptive_small) {
         // issue-to-landing time of the single-launch path (the search thread has been polling since the issue)
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_issue).count();
         s->small_latency = s->small_seen == 0 ? dt : 0.8 * s->small_latency + 0.2 * dt;
         if (++s->small_seen >= 16 && s->small_latency > 70e-6) { s->pipeline_left = 2000; s->small_seen = 0; }
-        s->inflight_small = false;
     }
-    if (src == s) s->inflight_zero_copy = false;
+    if (src == s) { s->inflight_small = false; s->inflight_zero_copy = false; }
     for (int i = 0; i < B; ++i) {
         const int sid = batch[i];
         s->cache_off[sid] = (int64_t)s->recs.size();
@@ -615,6 +615,7 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
 
 int run_batch(smplx_space* s, int id)
 {
+    s->adaptive_small = true;   // synchronous: the landing time is the GPU's
     if (int e = issue_batch(s, id)) return e;
     if (int e = wait_event_polling(s->batch_done)) return e;
     return collect_batch(s);
@@ -1557,6 +1558,8 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
         if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
         fill_search(S[q], s, p);
+        s->adaptive_small = nq == 1;
+        if (nq > 1) s->pipeline_left = 0;
         s->expansion_log.clear();
         const int capB = s->params.batch_states > 0 ? s->params.batch_states : 4096;
         cw[q] = counter_words(capB, s->M);
