@@ -76,6 +76,17 @@ int main(int argc, char** argv)
     std::vector<int> ids{space->getStartStateID()};
     std::vector<RobotState> states;
     if (!space->extractPath(ids, states) || states[0] != start) return 6;
+    // PlannerInterface::postProcessPath through the mirror: shortcut + interpolate (upstream limit test) of a short path
+    if (frontier.size() > 5) {
+        std::vector<int> pid{frontier[0], frontier[1], frontier[5]};
+        std::vector<RobotState> pp;
+        if (!space->extractPath(pid, pp)) return 7;
+        if (!PostProcessPath(&ctx, pp, true, true, true)) return 8;
+        printf("post %zu", pp.size());
+        for (double v : pp.back()) printf(" %.17g", v);
+        for (double v : pp[pp.size() / 2]) printf(" %.17g", v);
+        printf("\n");
+    }
     printf("done\n");
     return 0;
 }

@@ -52,4 +52,10 @@ def test_cpp_plugin_driver_matches_oracle(small_cfg, tmp_path):
                 frontier.append(int(a))
         assert lines[k] == exp
         k += 1
+    if len(frontier) > 5:
+        P = np.array([o.get_state(frontier[i])[0] for i in (0, 1, 5)])
+        want, _, _ = o.post_process(P, True, True, True)
+        exp = f"post {len(want)}" + "".join(f" {v:.17g}" for v in want[-1]) + "".join(f" {v:.17g}" for v in want[len(want) // 2])
+        assert lines[k] == exp
+        k += 1
     assert lines[k] == "done"
