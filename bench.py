@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="timed steps whose kernels are bracketed by HIP events (default: steps/8, at least 1); every "
                          "event costs the stream a marker, about 3 us, three of them per profiled step")
+    ap.add_argument("--scaling-batches", type=str, default="16384,65536",
+                    help="secondary figure: the same step at larger frontier batches (comma list, empty to skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--generic-kernels", action="store_true", help="skip the per-robot hiprtc build (A/B runs)")
@@ -224,6 +226,47 @@ def main():
         t1o = time.perf_counter()
         out["overlapped"] = {"streams": S_, "steps": nst, "ms_per_step": round(1e3 * (t1o - t0o) / nst, 4),
                              "successor_evaluations_per_s": round(evals / max(args.steps, 1) * nst / (t1o - t0o), 1)}
+
+    if rank == 0 and world == 1 and args.scaling_batches:
+        # secondary figure: the step at larger frontier batches (the kernels are latency-bound at B=4096: about two
+        # waves per SIMD).  Same scene and query; the frontier is the first B2 states a longer search creates.  Not `value`.
+        out["batch_scaling"] = {}
+        for B2 in [int(x) for x in args.scaling_batches.split(",") if x]:
+            sp = capi.Space.from_config(cfg, batch_states=4096, generic_kernels=args.generic_kernels)
+            sp.set_goal_joint(goal, cfg.goal_tol)
+            sp.set_start(cfg.start)
+            nw = max(1500, B2 // 3)
+            while sp.num_states() <= B2 and nw <= 4 * B2:
+                sp.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nw, nw)
+                nw *= 2
+            if sp.num_states() <= B2:
+                continue
+            Q2 = np.stack([sp.get_state(i)[0] for i in range(1, B2 + 1)])
+            t = {k: torch.zeros(B2 * M * w, dtype=dt, device=dev) for k, w, dt in
+                 [("flags", 1, torch.uint8), ("coord", N, torch.int32), ("sq", N, torch.float64), ("h", 1, torch.int32),
+                  ("cost", 1, torch.int32), ("lk", 1, torch.int32)]}
+            q2 = torch.from_numpy(Q2).to(dev)
+            w2 = torch.zeros(sp.expand_work_bytes(B2), dtype=torch.uint8, device=dev)
+            c2 = torch.zeros(sp.counters_bytes(B2) // 8, dtype=torch.int64, device=dev)
+
+            def step2():
+                sp.expand_batch_device(q2.data_ptr(), B2, t["flags"].data_ptr(), t["coord"].data_ptr(), t["sq"].data_ptr(),
+                                       t["h"].data_ptr(), t["cost"].data_ptr(), t["lk"].data_ptr(), w2.data_ptr(),
+                                       c2.data_ptr(), stream.cuda_stream)
+            for _ in range(3):
+                step2()
+            torch.cuda.synchronize()
+            c2.zero_()
+            n2 = 20
+            ta = time.perf_counter()
+            for _ in range(n2):
+                step2()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            ev2 = sp.counters_read(c2.data_ptr(), B2)[0]
+            out["batch_scaling"][str(B2)] = {"ms_per_step": round(1e3 * (tb - ta) / n2, 4),
+                                             "successor_evaluations_per_s": round(ev2 / (tb - ta), 1)}
+            del sp, t, q2, w2, c2
 
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
