@@ -410,6 +410,22 @@ int orc_post_process(void* h, const double* path, int n, int mode, double* out, 
     return (int)p.size();
 }
 
+// the shortcut loop alone, answered from tables (same interface as oracle/shortcut_ref_driver.cpp): P points,
+// cost[P*P], valid[P*P]; returns the number of output indices
+int orc_shortcut_tables(int P, const double* cost, const int* valid, int* out)
+{
+    std::vector<double> seg;
+    for (int i = 0; i + 1 < P; ++i) seg.push_back(cost[(size_t)i * P + i + 1]);
+    std::vector<int> idx;
+    shortcut_indices((size_t)P, seg, [&](size_t a, size_t b, double& c) {
+        if (!valid[a * P + b]) return false;
+        c = cost[a * P + b];
+        return true;
+    }, idx);
+    std::copy(idx.begin(), idx.end(), out);
+    return (int)idx.size();
+}
+
 // --- intrusive heap exerciser: ops[i] = {code, key}; codes 0 push(new elem with key), 1 pop,
 // 2 decrease(elem index key>>20 to priority key&0xFFFFF), 3 erase(elem index key), 4 make (after
 // rewriting all priorities p -> (p*7919+13)%1000), 5 increase(elem, priority).  Emits the element

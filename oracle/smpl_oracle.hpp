@@ -8,14 +8,16 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 // include, link or execute this.  The product (smpl_amd/) never does.
 //
-// PARITY STATUS: "parity unpinned" for everything except the intrusive heap.
-// The reference cannot be built here (Eigen, Boost, SBPL, ROS, KDL, urdf are
-// absent; smpl/config.h is cmake-generated), and its own tests hold no numeric
-// golden vectors for this path.  The one header-only,
-// std-only piece -- smpl/include/smpl/intrusive_heap.h -- is compiled in place
-// by oracle/Makefile into oracle/_ref/heap_ref and pins IntrusiveHeap below
-// (tests/golden/heap_ref_*.json).  Everything else follows the cited reference
-// lines and is pinned by hand-derived known-answer tests (tests/test_oracle_kat.py).
+// PARITY STATUS: "parity unpinned" for everything except the intrusive heap and
+// the path shortcutting loop.  The reference cannot be built here (Eigen, Boost,
+// SBPL, ROS, KDL, urdf are absent; smpl/config.h is cmake-generated), and its own
+// tests hold no numeric golden vectors for this path.  The
+// two header-only, std-only pieces -- smpl/include/smpl/intrusive_heap.h and
+// smpl/include/smpl/geometry/shortcut.h -- are compiled in place by oracle/Makefile
+// into oracle/_ref/ and pin IntrusiveHeap and shortcut_indices below
+// (tests/golden/heap_ref.json, tests/golden/shortcut_ref.json).  Everything else
+// follows the cited reference lines and is pinned by hand-derived known-answer
+// tests (tests/test_oracle_kat.py).
 //
 // Third-party arithmetic that is NOT in /root/reference (orocos-kdl FK, Eigen
 // products, libm sin/cos) is restated with the "arithmetic contract" of
@@ -1645,6 +1647,63 @@ struct ManipLattice {
 // smpl_ros/src/ros/planner_interface.cpp:2651-2697.
 // ---------------------------------------------------------------------------
 
+// The loop of sbpl::shortcut::ShortcutPath (smpl/include/smpl/geometry/detail/shortcut.hpp:110-286) over point INDICES,
+// one generator that returns the two-point path {start, end} (post_processing.cpp:100-127), window 1, granularity 1,
+// comparator std::less_equal.  seg[i] = cost of the original transition i -> i+1.  Pinned against the reference's own
+// header compiled in place (oracle/_ref/shortcut_ref, tests/golden/shortcut_ref.json).
+template <class Generate>
+inline void shortcut_indices(size_t psize, const std::vector<double>& seg, Generate generate, std::vector<int>& out)
+{
+    out.clear();
+    if (psize == 0) return;
+    if (psize < 2) { out.push_back(0); return; }
+    std::vector<double> accum(psize);
+    accum[0] = 0.0;
+    for (size_t i = 1; i < psize; ++i) accum[i] = accum[i - 1] + seg[i - 1];
+    const size_t granularity = 1;
+    size_t start = 0, end = std::min(psize - 1, granularity);
+    // the best path of the segment of interest: either the original points [start, end] or a direct connection
+    bool best_direct = false;
+    size_t best_last = end;            // last original index the best path reaches
+    double best_cost = accum[end] - accum[start];
+    double cost = 0.0;
+    if (generate(start, end, cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
+    out.push_back(0);
+    auto emit_best = [&]() {
+        if (best_direct) out.push_back((int)best_last);
+        else for (size_t i = start + 1; i <= best_last; ++i) out.push_back((int)i);
+    };
+    while (end != psize) {
+        bool improved = false;
+        const size_t look_dist = std::min(granularity, psize - end - 1);   // distance(curr_end, plast) - 1
+        if (look_dist != 0) {
+            const double exp_cost = accum[end + look_dist] - accum[end];
+            double new_cost = best_cost + exp_cost;
+            if (generate(start, end + look_dist, cost) && cost <= new_cost) {
+                improved = true;
+                best_direct = true;
+                best_last = end + look_dist;
+                new_cost = cost;
+            }
+            best_cost = new_cost;
+        }
+        if (improved) {
+            end += look_dist;
+        } else if (look_dist == 0) {
+            end = psize;
+        } else {
+            emit_best();
+            start = end;
+            end += look_dist;
+            best_direct = false;
+            best_last = end;
+            best_cost = accum[end] - accum[start];
+            if (generate(start, end, cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
+        }
+    }
+    emit_best();
+}
+
 struct PostProcessor {
     PlanningRobotModel* robot;
     CollisionSpace* cc;
@@ -1675,51 +1734,11 @@ struct PostProcessor {
         pout.clear();
         const size_t psize = pin.size();
         if (psize < 2) { pout = pin; return; }
-        std::vector<double> accum(psize);
-        accum[0] = 0.0;
-        for (size_t i = 1; i < psize; ++i) accum[i] = accum[i - 1] + distance(pin[i - 1], pin[i]);
-        const size_t granularity = 1;
-        size_t start = 0, end = std::min(psize - 1, granularity);
-        // the best path of the segment of interest: either the original points [start, end] or a direct connection
-        bool best_direct = false;
-        size_t best_last = end;            // last original index the best path reaches
-        double best_cost = accum[end] - accum[start];
-        double cost = 0.0;
-        if (generate(pin[start], pin[end], cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
-        pout.push_back(pin[0]);
-        auto emit_best = [&]() {
-            if (best_direct) pout.push_back(pin[best_last]);
-            else for (size_t i = start + 1; i <= best_last; ++i) pout.push_back(pin[i]);
-        };
-        while (end != psize) {
-            bool improved = false;
-            const size_t look_dist = std::min(granularity, psize - end - 1);   // distance(curr_end, plast) - 1
-            if (look_dist != 0) {
-                const double exp_cost = accum[end + look_dist] - accum[end];
-                double new_cost = best_cost + exp_cost;
-                if (generate(pin[start], pin[end + look_dist], cost) && cost <= new_cost) {
-                    improved = true;
-                    best_direct = true;
-                    best_last = end + look_dist;
-                    new_cost = cost;
-                }
-                best_cost = new_cost;
-            }
-            if (improved) {
-                end += look_dist;
-            } else if (look_dist == 0) {
-                end = psize;
-            } else {
-                emit_best();
-                start = end;
-                end += look_dist;
-                best_direct = false;
-                best_last = end;
-                best_cost = accum[end] - accum[start];
-                if (generate(pin[start], pin[end], cost) && cost <= best_cost) { best_direct = true; best_cost = cost; }
-            }
-        }
-        emit_best();
+        std::vector<double> seg(psize - 1);
+        for (size_t i = 0; i + 1 < psize; ++i) seg[i] = distance(pin[i], pin[i + 1]);   // ComputePositionPathCosts (:430-445)
+        std::vector<int> idx;
+        shortcut_indices(psize, seg, [&](size_t a, size_t b, double& cost) { return generate(pin[a], pin[b], cost); }, idx);
+        for (int i : idx) pout.push_back(pin[i]);
     }
     // collision_space.cpp:583-612 + 776-793
     bool withinLimits(const std::vector<double>& q) const
