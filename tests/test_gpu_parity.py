@@ -431,6 +431,25 @@ def test_sphere_padding(small_cfg, padding):
     _compare_expand(o, s, Q[ok.astype(bool)][:40])
 
 
+def test_reference_mprim_file_through_the_c_abi(small_cfg):
+    """The reference's own smpl_test/config/pr2.mprim (tests/golden/pr2.mprim, upstream row format) handed to
+    smplx_space_create as it is."""
+    import copy
+    import os
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = copy.copy(small_cfg)
+    cfg.mprim = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pr2.mprim")).read()
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg)
+    s.fused = False
+    assert s.M == o.M == 25
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    _compare_expand(o, s, np.vstack([np.array(cfg.start), _random_states(40, 61)]))
+
+
 @pytest.mark.parametrize("long_and_short", [False, True])
 def test_fork_mprim_rows_with_weights_and_long_and_short_gating(small_cfg, long_and_short):
     """[FORK] .mprim rows carry a group and a weight after the deltas (manip_lattice_action_space.cpp:149,161-186):
