@@ -1327,8 +1327,9 @@ struct Search {
         int n = 0;
         error = get_succs(sp, sid, &succs, &costs, &n);   // served from the cache: improve_path checked ready(sid)
         if (error) return;
-        // copies: get_succs of a later state may grow the committed arrays
-        std::vector<int32_t> ss(succs, succs + n), cc(costs, costs + n);
+        // succs/costs point into the committed arrays, which only get_succs grows: nothing below calls it
+        const int32_t* ss = succs;
+        const int32_t* cc = costs;
         const unsigned int eg = st[sid].eg;
         for (int i = 0; i < n; ++i) {
             const int nid = ss[i];
