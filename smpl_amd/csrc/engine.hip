@@ -333,7 +333,7 @@ int run_bfs(smplx_space* s, const double xyz[3])
     const int chunk = 32;
     while (true) {
         for (int k = 0; k < chunk; ++k, ++level) {
-            hipLaunchKernelGGL(k_bfs_level, dim3(1024), dim3(256), 0, s->stream, s->d_bfs, s->d_queue[level & 1],
+            hipLaunchKernelGGL(k_bfs_level, dim3(512), dim3(512), 0, s->stream, s->d_bfs, s->d_queue[level & 1],
                                s->d_queue[(level + 1) & 1], s->d_counts, level, dx, dx * dy);
         }
         HIP_TRY(hipGetLastError());

@@ -1787,32 +1787,62 @@ k_bfs_seed(int* __restrict__ dist, int origin, int* __restrict__ queue, int* __r
 
 // counts[level % 3] = size of the input frontier, counts[(level + 1) % 3] = size of the output frontier;
 // counts[(level + 2) % 3] (the previous input) is cleared here for the level after next.
-extern "C" __global__ void __launch_bounds__(256)
+#define SMPLX_BFS_BLOCK 512
+
+extern "C" __global__ void __launch_bounds__(SMPLX_BFS_BLOCK)
 k_bfs_level(int* __restrict__ dist, const int* __restrict__ q_in, int* __restrict__ q_out, int* __restrict__ counts,
             int level, int dim_x, int dim_xy)
 {
+    // Appending every discovered cell to the next frontier through one counter is what a level costs: same-address
+    // atomics serialise at ~12 ns, and even one per wave (the compiler's aggregation) is 5 000 of them on a 3*10^5-cell
+    // frontier.  So a thread keeps the cells it won in registers, the block adds up its threads' counts, claims ONE
+    // range of the queue, and every thread writes its cells into its part of the range.  (The order of the queue does
+    // not matter to the distances.)
+    __shared__ int wave_total[SMPLX_BFS_BLOCK / 64];
+    __shared__ int block_base;
     const int n_in = counts[level % 3];
     int* n_out = &counts[(level + 1) % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[(level + 2) % 3] = 0;
     const int w = dim_x, p = dim_xy;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_in; i += gridDim.x * 256) {
-        const int cur = q_in[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i0 = blockIdx.x * SMPLX_BFS_BLOCK; i0 < n_in; i0 += gridDim.x * SMPLX_BFS_BLOCK) {   // uniform per block
+        const int i = i0 + threadIdx.x;
+        int won[26];
+        int nwon = 0;
+        if (i < n_in) {
+            const int cur = q_in[i];
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz) {
+            for (int dz = -1; dz <= 1; ++dz) {
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
+                for (int dy = -1; dy <= 1; ++dy) {
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dx == 0 && dy == 0 && dz == 0) continue;
-                    const int nb = cur + dz * p + dy * w + dx;
-                    if (dist[nb] < 0) {
-                        if (atomicCAS(&dist[nb], -1, level + 1) == -1) {
-                            const int slot = atomicAdd(n_out, 1);
-                            q_out[slot] = nb;
-                        }
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dx == 0 && dy == 0 && dz == 0) continue;
+                        const int nb = cur + dz * p + dy * w + dx;
+                        if (dist[nb] < 0 && atomicCAS(&dist[nb], -1, level + 1) == -1) won[nwon++] = nb;
                     }
                 }
             }
         }
+        // exclusive prefix of nwon over the block
+        int incl = nwon;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wave_total[wv] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < SMPLX_BFS_BLOCK / 64; ++k) tot += wave_total[k];
+            block_base = tot > 0 ? atomicAdd(n_out, tot) : 0;
+        }
+        __syncthreads();
+        int first = block_base + incl - nwon;
+        for (int k = 0; k < wv; ++k) first += wave_total[k];
+        for (int k = 0; k < nwon; ++k) q_out[first + k] = won[k];
+        __syncthreads();   // wave_total / block_base are reused by the next round
     }
 }
