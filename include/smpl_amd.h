@@ -11,6 +11,8 @@
  *     smpl/include/smpl/types.h:66)
  *   - host pointers are copied during the call; "_device" variants take pointers into HBM and a
  *     hipStream_t (passed as void*) and do not synchronise
+ *   - joint values handed in through host pointers must be finite with |q| < 1e6 (SMPLX_E_ARG otherwise: the limit
+ *     folding of KDLRobotModel::checkJointLimits would not terminate on them); "_device" variants cannot check
  *   - calls on one handle are serialised by the caller, like the reference's single-threaded
  *     plugins (sbpl_collision_checking/src/collision_space.cpp:741-774 mutates state per query)
  */
@@ -76,7 +78,9 @@ typedef struct smplx_params {
     int32_t use_xyzrpy_snap_mprim;    /* joint-space goals only: the action is the goal itself
                                          (manip_lattice_action_space.cpp:551-559) */
     double xyzrpy_snap_dist_thresh;
-    int32_t xy_rotate_by_var3;        /* [FORK] manip_lattice_action_space.cpp:590-599 */
+    int32_t xy_rotate_by_var3;        /* [FORK] manip_lattice_action_space.cpp:590-599 rotates delta[0], delta[1] by
+                                         state[3] in every applyMotionPrimitive: 1 = the reference's behaviour (what
+                                         every caller of this repo passes unless it asks for upstream smpl), 0 = upstream */
     int32_t use_long_and_short;
     double padding;                   /* SelfCollisionModel m_padding, default 0 */
     int32_t batch_states;             /* frontier batch B (0 = default 4096) */
@@ -107,6 +111,10 @@ int smplx_space_num_vars(const smplx_space* s);
 int smplx_space_num_prims(const smplx_space* s);
 int smplx_space_discretization(const smplx_space* s, int32_t* coord_vals, double* coord_deltas);
 
+/* RobotModel::checkJointLimits as KDLRobotModel implements it (sbpl_kdl_robot_model/src/kdl_robot_model.cpp:173-189,
+ * 210-235: fold by 2*pi into [min, min + 2*pi), then compare with the limits); host arithmetic, n states */
+int smplx_check_joint_limits(const smplx_space* s, const double* q, int n, uint8_t* ok);
+
 /* ---- CollisionChecker (smpl/include/smpl/collision_checker.h:48-130) ---- */
 /* isStateValid (collision_space.cpp:532-536) */
 int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* valid, int32_t* lookups);
@@ -127,6 +135,13 @@ int smplx_set_goal_xyz(smplx_space* s, const double xyz[3], const double tol[3])
 int smplx_goal_pose(const smplx_space* s, double xyz[3]);
 /* GetGoalHeuristic for arbitrary states (bfs_heuristic.cpp:148-163); xyz (n*3) may be NULL */
 int smplx_heuristic_batch(smplx_space* s, const double* q, int n, int32_t* h, double* xyz);
+/* BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138) for n workspace points xyz[n*3]:
+ * BFS cell distance * resolution, WALL * resolution outside the grid.  This is the value the action space gates the
+ * short / snap primitives on (manip_lattice_action_space.cpp:393-397). */
+int smplx_bfs_metric_goal_distance(smplx_space* s, const double* xyz, int n, double* out);
+/* BfsHeuristic::getMetricStartDistance (bfs_heuristic.cpp:103-127): Manhattan cell distance to the cell of the start
+ * state's planning link, times the resolution (needs smplx_set_start) */
+int smplx_bfs_metric_start_distance(smplx_space* s, const double* xyz, int n, double* out);
 /* the padded (nx+2)(ny+2)(nz+2) BFS_3D distance grid, node order of bfs3d.h:213-220 */
 int64_t smplx_bfs_size(const smplx_space* s);
 int smplx_bfs_copy(smplx_space* s, int32_t* out);
@@ -165,8 +180,16 @@ int smplx_start_id(const smplx_space* s);
 int smplx_goal_id(const smplx_space* s);   /* always 0 (manip_lattice.cpp:122) */
 /* GetSuccs (manip_lattice.cpp:219-313): valid successors of a state id in primitive order */
 int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int cap, int* n);
-/* optional: ids the caller expects to expand soon (top of OPEN); they ride along in the next batch */
+/* optional: ids the caller expects to expand soon (top of OPEN); they ride along in the next batch.  A caller that
+ * never hints (an unchanged SBPL planner) still gets frontier batches: the space mirrors the g-values the caller's
+ * GetSuccs sequence implies (arastar.cpp:546-551) and lets the unevaluated states with the smallest g + w*h ride
+ * along on every miss (env SMPLX_AUTO_SPECULATE = states per miss, default 96, 0 = off; SMPLX_AUTO_SPECULATE_W = w,
+ * default 5).  Speculation never changes results: ids are assigned when the caller's own sequence commits a state. */
 int smplx_hint_frontier(smplx_space* s, const int32_t* ids, int n);
+/* GetSuccs has no way to report a failure to an SBPL caller (the successor list just stays empty, which reads as a
+ * dead end): the first such error is kept on the space.  Returns SMPLX_OK or that error code; msg gets its text. */
+int smplx_space_status(const smplx_space* s, char* msg, int cap);
+void smplx_space_clear_status(smplx_space* s);
 /* RobotHeuristic::GetGoalHeuristic(state_id) */
 int smplx_get_goal_heuristic(smplx_space* s, int id, int32_t* h);
 int smplx_num_states(const smplx_space* s);

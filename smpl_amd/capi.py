@@ -30,6 +30,8 @@ SYMBOLS = [
     "smplx_get_succs", "smplx_hint_frontier", "smplx_get_goal_heuristic", "smplx_num_states", "smplx_get_state",
     "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_post_process_path", "smplx_space_specialized", "smplx_model_const_header", "smplx_profile_begin",
     "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read", "smplx_plan_multi",
+    "smplx_bfs_metric_goal_distance", "smplx_bfs_metric_start_distance", "smplx_space_status", "smplx_space_clear_status",
+    "smplx_check_joint_limits",
 ]
 
 
@@ -79,6 +81,10 @@ def lib():
         L.smplx_counters_bytes.restype = C.c_size_t
         L.smplx_counters_bytes.argtypes = [C.c_void_p, C.c_int]
         L.smplx_counters_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _u64p]
+        L.smplx_bfs_metric_goal_distance.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.smplx_bfs_metric_start_distance.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.smplx_space_clear_status.argtypes = [C.c_void_p]
+        L.smplx_space_clear_status.restype = None
         _lib = L
     return _lib
 
@@ -221,6 +227,12 @@ class Space:
         _chk(lib().smplx_space_discretization(self.h, _p(v, _ip), _p(d, _dp)))
         return v, d
 
+    def check_joint_limits(self, q):
+        q = _f64(q).reshape(-1, self.N); out = np.zeros(q.shape[0], np.uint8)
+        lib().smplx_check_joint_limits.argtypes = [C.c_void_p, _dp, C.c_int, _up]
+        _chk(lib().smplx_check_joint_limits(self.h, _p(q, _dp), q.shape[0], _p(out, _up)))
+        return out
+
     # ---- CollisionChecker ----
     def state_valid_batch(self, q):
         q = _f64(q).reshape(-1, self.N); n = q.shape[0]
@@ -264,6 +276,21 @@ class Space:
         h = np.zeros(n, np.int32); xyz = np.zeros((n, 3))
         _chk(lib().smplx_heuristic_batch(self.h, _p(q, _dp), n, _p(h, _ip), _p(xyz, _dp)))
         return h, xyz
+
+    def metric_goal_distance(self, xyz):
+        xyz = _f64(xyz).reshape(-1, 3); out = np.zeros(xyz.shape[0])
+        _chk(lib().smplx_bfs_metric_goal_distance(self.h, _p(xyz, _dp), xyz.shape[0], _p(out, _dp)))
+        return out
+
+    def metric_start_distance(self, xyz):
+        xyz = _f64(xyz).reshape(-1, 3); out = np.zeros(xyz.shape[0])
+        _chk(lib().smplx_bfs_metric_start_distance(self.h, _p(xyz, _dp), xyz.shape[0], _p(out, _dp)))
+        return out
+
+    def status(self):
+        buf = C.create_string_buffer(1024)
+        lib().smplx_space_status.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        return lib().smplx_space_status(self.h, buf, 1024), buf.value.decode(errors="replace")
 
     def bfs_grid(self):
         n = lib().smplx_bfs_size(self.h)

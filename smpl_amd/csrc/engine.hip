@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <thread>
@@ -31,6 +32,15 @@ int set_error(int code, const std::string& msg)
 {
     g_error = msg;
     return code;
+}
+
+// input guard of the entry points that take joint values from the caller: a non-finite or absurd value would make the
+// limit folding of KDLRobotModel::checkJointLimits (a -= 2*pi until in range) spin forever on the device
+bool sane_values(const double* q, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!(q[i] > -1.0e6 && q[i] < 1.0e6)) return false;
+    return true;
 }
 
 #define HIP_TRY(expr)                                                                                   \
@@ -194,6 +204,9 @@ struct smplx_space {
     int wall_thr = -1;
     bool goal_set = false;
     double goal_xyz[3] = {0, 0, 0};
+    double start_xyz[3] = {0, 0, 0};   // planning-link position of the start state (getMetricStartDistance)
+    int status = SMPLX_OK;            // sticky: first error of a call that has no way to report one (smplx_space_status)
+    std::string status_msg;
     // scratch
     DevBuf<double> b_q, b_q2, b_sq, b_xyz;
     DevBuf<unsigned char> b_flags, b_work;
@@ -226,6 +239,15 @@ struct smplx_space {
     std::vector<int32_t> done_cnt;
     std::vector<int32_t> done_succ, done_cost;
     std::vector<int32_t> hint;
+    // Speculation for callers that only know GetSuccs (an unchanged SBPL planner never calls smplx_hint_frontier): the
+    // space mirrors the g-values the caller's expansions imply (g[succ] = min(g[succ], g[id] + cost), exactly what
+    // ARAStar::expand does, arastar.cpp:546-551) and, on a miss, lets the created-but-unevaluated states with the
+    // smallest g + w*h ride along.  Only a guess at the caller's OPEN order: a wrong guess costs GPU work, never results.
+    bool plain_mode = false;            // set by the first smplx_get_succs from outside the engine's own search
+    int auto_spec = 96;                 // states that ride along per miss (SMPLX_AUTO_SPECULATE, 0 = off)
+    double auto_w = 5.0;                // weight of h in the ranking (SMPLX_AUTO_SPECULATE_W)
+    std::vector<uint32_t> g_est;        // per id, mirrored g (plain mode only)
+    std::vector<std::pair<uint64_t, int32_t>> pool;   // binary min-heap of (rank key, id) of unevaluated states
     // a frontier batch in flight (issued on `stream`, completion signalled by `batch_done`)
     std::vector<int32_t> inflight;
     hipEvent_t batch_done = nullptr;
@@ -475,7 +497,38 @@ int new_state(smplx_space* s, const int32_t* coord, const double* q, int32_t h)
     s->done_cnt.push_back(0);
     s->eval_count.push_back(0);
     s->table.insert(id, s->coords);
+    if (s->plain_mode) s->g_est.push_back(1000000000u);
     return id;
+}
+
+// plain-GetSuccs speculation pool (see smplx_space::plain_mode)
+inline uint64_t pool_key(const smplx_space* s, int id)
+{
+    const int32_t h = s->h_of_id[id];
+    const double k = (double)s->g_est[id] + s->auto_w * (double)(h < 0 ? 0 : h);
+    return k >= 1.8e19 ? ~0ull : (uint64_t)k;
+}
+
+inline void pool_push(smplx_space* s, int id)
+{
+    s->pool.emplace_back(pool_key(s, id), id);
+    std::push_heap(s->pool.begin(), s->pool.end(), std::greater<std::pair<uint64_t, int32_t>>());
+}
+
+// fill s->hint with the best-ranked states that are neither evaluated nor committed
+void auto_hint(smplx_space* s, int miss_id)
+{
+    s->hint.clear();
+    const auto cmp = std::greater<std::pair<uint64_t, int32_t>>();
+    while (!s->pool.empty() && (int)s->hint.size() < s->auto_spec) {
+        std::pop_heap(s->pool.begin(), s->pool.end(), cmp);
+        const std::pair<uint64_t, int32_t> top = s->pool.back();
+        s->pool.pop_back();
+        const int id = top.second;
+        if (id == miss_id || s->cache_off[id] != -1 || s->done_off[id] >= 0) continue;   // evaluated meanwhile
+        if (top.first != pool_key(s, id)) continue;                                        // a better-ranked copy exists
+        s->hint.push_back(id);
+    }
 }
 
 void reset_lattice(smplx_space* s)
@@ -485,6 +538,9 @@ void reset_lattice(smplx_space* s)
     s->done_off.clear(); s->done_cnt.clear(); s->done_succ.clear(); s->done_cost.clear();
     s->eval_count.clear();
     s->hint.clear();
+    s->pool.clear();
+    s->g_est.clear();
+    s->plain_mode = false;
     s->table.init(s->N);
     s->start_id = -1;
     // id 0 is reserved for the goal (manip_lattice.cpp:122); it has no coordinate and is never hashed
@@ -515,13 +571,33 @@ void select_batch(smplx_space* s, int id, int cap)
 }
 
 // A frontier batch takes tens of microseconds; an interrupt-driven hipEventSynchronize adds about as much again to
-// wake the thread up.  The search thread has nothing else to do, so it polls.
+// wake the thread up.  The search thread has nothing else to do, so it polls -- with a deadline: a batch that has not
+// landed after SMPLX_BATCH_TIMEOUT_S seconds (default 30; a batch takes well under a millisecond) is a hung kernel,
+// and the caller gets SMPLX_E_HIP instead of a thread that never returns (include/smpl_amd.h: every function returns).
+double batch_timeout_seconds()
+{
+    static const double t = [] {
+        const char* e = getenv("SMPLX_BATCH_TIMEOUT_S");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 30.0;
+    }();
+    return t;
+}
+
 int wait_event_polling(hipEvent_t ev)
 {
-    while (true) {
+    std::chrono::steady_clock::time_point t0;
+    bool timing = false;
+    for (unsigned spins = 0;; ++spins) {
         const hipError_t st = hipEventQuery(ev);
         if (st == hipSuccess) return SMPLX_OK;
         if (st != hipErrorNotReady) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+        if ((spins & 0x3FFF) == 0x3FFF) {   // look at the clock every 16k polls (a few milliseconds)
+            const auto now = std::chrono::steady_clock::now();
+            if (!timing) { t0 = now; timing = true; }
+            else if (std::chrono::duration<double>(now - t0).count() > batch_timeout_seconds())
+                return set_error(SMPLX_E_HIP, "frontier batch did not complete within SMPLX_BATCH_TIMEOUT_S: kernel hung?");
+        }
     }
 }
 
@@ -629,6 +705,7 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
     if (s->done_off[id] < 0) {
         if (s->cache_off[id] < 0) {
             ++s->cache_misses;   // plain GetSuccs callers (the unchanged ARA* of smpl): synchronous batch
+            if (s->plain_mode && s->hint.empty() && s->auto_spec > 0) auto_hint(s, id);
             if (int e = run_batch(s, id)) return e;
         } else {
             ++s->cache_hits;
@@ -647,6 +724,19 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
         s->done_off[id] = dof;
         s->done_cnt[id] = cnt;
         s->committed_evals += s->eval_count[id];
+    }
+    if (s->plain_mode) {
+        // the caller is expanding `id` now: mirror its g-updates and (re)rank the successors not yet evaluated
+        const uint32_t gp = s->g_est[id];
+        for (int k = 0; k < s->done_cnt[id]; ++k) {
+            const int sid = s->done_succ[s->done_off[id] + k];
+            if (sid == 0 || gp >= 1000000000u) continue;
+            const uint32_t g = gp + (uint32_t)s->done_cost[s->done_off[id] + k];
+            if (g < s->g_est[sid]) {
+                s->g_est[sid] = g;
+                if (s->cache_off[sid] == -1 && s->done_off[sid] < 0) pool_push(s, sid);
+            }
+        }
     }
     *n = s->done_cnt[id];
     *succs = s->done_succ.data() + s->done_off[id];
@@ -793,6 +883,8 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->fused_mode = (params->reserved & 1) != 0;
     s->tiny_work_list = (params->reserved & 2) != 0;
     if (params->reserved & 4) s->small_batch_max = 0;
+    if (const char* e = getenv("SMPLX_AUTO_SPECULATE")) s->auto_spec = std::max(0, atoi(e));
+    if (const char* e = getenv("SMPLX_AUTO_SPECULATE_W")) s->auto_w = atof(e);
     s->N = s->model.dev.nvars;
     if (!smplx::load_mprim_text(mprim_text, params->resolutions, s->N, s->actions)) {
         const std::string err = s->actions.error;
@@ -902,10 +994,19 @@ int smplx_space_discretization(const smplx_space* s, int32_t* coord_vals, double
     return SMPLX_OK;
 }
 
+int smplx_check_joint_limits(const smplx_space* s, const double* q, int n, uint8_t* ok)
+{
+    if (!s || !q || !ok || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (!sane_values(q, (size_t)n * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
+    for (int i = 0; i < n; ++i) ok[i] = host_check_limits(s->model.dev, q + (size_t)i * s->N) ? 1 : 0;
+    return SMPLX_OK;
+}
+
 int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* valid, int32_t* lookups)
 {
     if (!s || !q || !valid || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
     if (n == 0) return SMPLX_OK;
+    if (!sane_values(q, (size_t)n * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     int e;
     if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
     if ((e = s->b_flags.reserve(n))) return e;
@@ -925,6 +1026,8 @@ int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, 
 {
     if (!s || !a || !b || !valid || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
     if (n == 0) return SMPLX_OK;
+    if (!sane_values(a, (size_t)n * s->N) || !sane_values(b, (size_t)n * s->N))
+        return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     int e;
     if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
     if ((e = s->b_q2.reserve((size_t)n * s->N))) return e;
@@ -946,6 +1049,7 @@ int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, 
 int smplx_cc_interpolate(smplx_space* s, const double* a, const double* b, double* out, int cap, int* n)
 {
     if (!s || !a || !b || !n) return set_error(SMPLX_E_ARG, "bad argument");
+    if (!sane_values(a, s->N) || !sane_values(b, s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     // waypoint count and interpolation are host arithmetic on det_math (collision_space.cpp:583-640,
     // robot_motion_collision_model.h:297-320); no grid or sphere data is involved
     const SmplxModelDev& M = s->model.dev;
@@ -974,6 +1078,7 @@ int smplx_cc_sphere_positions(smplx_space* s, const double* q, int n, double* ou
 {
     if (!s || !q || !out || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
     if (n == 0) return SMPLX_OK;
+    if (!sane_values(q, (size_t)n * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     int e;
     const size_t cnt = (size_t)n * s->model.dev.nnodes * 3;
     if ((e = s->b_q.reserve((size_t)n * s->N))) return e;
@@ -1007,6 +1112,7 @@ static int finish_goal(smplx_space* s)
 int smplx_set_goal_joint(smplx_space* s, const double* angles, const double* tolerances)
 {
     if (!s || !angles || !tolerances) return set_error(SMPLX_E_ARG, "null argument");
+    if (!sane_values(angles, s->N)) return set_error(SMPLX_E_ARG, "goal angles must be finite (|q| < 1e6)");
     SmplxGoalDev& G = s->hs.goal;
     G.type = SMPLX_GOAL_JOINT;
     for (int v = 0; v < s->N; ++v) { G.angles[v] = angles[v]; G.angle_tol[v] = tolerances[v]; }
@@ -1020,6 +1126,7 @@ int smplx_set_goal_joint(smplx_space* s, const double* angles, const double* tol
 int smplx_set_goal_xyz(smplx_space* s, const double xyz[3], const double tol[3])
 {
     if (!s || !xyz || !tol) return set_error(SMPLX_E_ARG, "null argument");
+    if (!sane_values(xyz, 3)) return set_error(SMPLX_E_ARG, "goal position must be finite");
     SmplxGoalDev& G = s->hs.goal;
     G.type = SMPLX_GOAL_XYZ;
     for (int a = 0; a < 3; ++a) { s->goal_xyz[a] = xyz[a]; G.xyz_tol[a] = tol[a]; }
@@ -1037,6 +1144,7 @@ int smplx_heuristic_batch(smplx_space* s, const double* q, int n, int32_t* h, do
 {
     if (!s || !q || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
     if (n == 0) return SMPLX_OK;
+    if (!sane_values(q, (size_t)n * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     return run_heuristic(s, q, n, h, xyz);
 }
 
@@ -1051,12 +1159,64 @@ int smplx_bfs_copy(smplx_space* s, int32_t* out)
     return SMPLX_OK;
 }
 
+int smplx_bfs_metric_goal_distance(smplx_space* s, const double* xyz, int n, double* out)
+{
+    if (!s || !xyz || !out || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+    if (n == 0) return SMPLX_OK;
+    if (!sane_values(xyz, (size_t)n * 3)) return set_error(SMPLX_E_ARG, "positions must be finite");
+    int e;
+    if ((e = s->b_xyz.reserve((size_t)n * 3))) return e;
+    if ((e = s->b_q2.reserve(n))) return e;
+    HIP_TRY(hipMemcpyAsync(s->b_xyz.p, xyz, sizeof(double) * n * 3, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_bfs_metric, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), 0, s->stream, s->hs.grid, s->hs.bfs, s->b_xyz.p, n,
+                       s->b_q2.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, s->b_q2.p, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+int smplx_bfs_metric_start_distance(smplx_space* s, const double* xyz, int n, double* out)
+{
+    if (!s || !xyz || !out || n < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
+    // bfs_heuristic.cpp:103-127: Manhattan distance in cells between the start's planning-link cell and the point's
+    const smplx_grid* g = s->grid;
+    auto cell = [&](const double* p, int c[3]) {
+        for (int a = 0; a < 3; ++a) c[a] = (int)(g->dev.inv_res * (p[a] - g->dev.origin_minus_res[a]) + 0.5) - 1;
+    };
+    int sc[3];
+    cell(s->start_xyz, sc);
+    for (int i = 0; i < n; ++i) {
+        int c[3];
+        cell(xyz + 3 * (size_t)i, c);
+        out[i] = g->res * (double)(std::abs(sc[0] - c[0]) + std::abs(sc[1] - c[1]) + std::abs(sc[2] - c[2]));
+    }
+    return SMPLX_OK;
+}
+
+int smplx_space_status(const smplx_space* s, char* msg, int cap)
+{
+    if (!s) return SMPLX_E_ARG;
+    if (msg && cap > 0) { std::strncpy(msg, s->status_msg.c_str(), cap - 1); msg[cap - 1] = 0; }
+    return s->status;
+}
+
+void smplx_space_clear_status(smplx_space* s)
+{
+    if (!s) return;
+    s->status = SMPLX_OK;
+    s->status_msg.clear();
+}
+
 int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q, int32_t* h,
                        int32_t* cost, int32_t* lookups)
 {
     if (!s || !q || B < 0) return set_error(SMPLX_E_ARG, "bad argument");
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first (the primitives are gated by goal distance)");
     if (B == 0) return SMPLX_OK;
+    if (!sane_values(q, (size_t)B * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     if (int e = reserve_expand(s, B)) return e;
     const size_t BM = (size_t)B * s->M;
     HIP_TRY(hipMemsetAsync(s->b_coord.p, 0, sizeof(int32_t) * BM * s->N, s->stream));
@@ -1145,6 +1305,7 @@ int smplx_set_start(smplx_space* s, const double* q, int* id)
 {
     if (!s || !q) return set_error(SMPLX_E_ARG, "null argument");
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "set the goal before the start (planner_interface.cpp:1469-1500 order)");
+    if (!sane_values(q, s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     if (!host_check_limits(s->model.dev, q)) return set_error(SMPLX_E_INVALID, "start state violates joint limits");
     uint8_t ok = 0;
     if (int e = smplx_cc_state_valid_batch(s, q, 1, &ok, nullptr)) return e;
@@ -1152,12 +1313,11 @@ int smplx_set_start(smplx_space* s, const double* q, int* id)
     std::vector<int32_t> c(s->N);
     state_to_coord(s->model.dev, q, c.data());
     int sid = s->table.find(c.data(), s->coords);
-    if (sid < 0) {
-        int32_t h = 0;
-        if (int e = run_heuristic(s, q, 1, &h, nullptr)) return e;
-        sid = new_state(s, c.data(), q, h);
-    }
+    int32_t h = 0;
+    if (int e = run_heuristic(s, q, 1, &h, s->start_xyz)) return e;   // also the start's planning-link position
+    if (sid < 0) sid = new_state(s, c.data(), q, h);
     s->start_id = sid;
+    if (s->plain_mode) { s->g_est.assign(s->h_of_id.size(), 1000000000u); s->g_est[sid] = 0; s->pool.clear(); }
     if (id) *id = sid;
     return SMPLX_OK;
 }
@@ -1169,9 +1329,20 @@ int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int 
 {
     if (!s || !n) return set_error(SMPLX_E_ARG, "null argument");
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+    if (!s->plain_mode) {
+        // first GetSuccs from outside: start mirroring the caller's g-values (the start has g = 0, arastar.cpp:172-176)
+        s->plain_mode = true;
+        s->g_est.assign(s->h_of_id.size(), 1000000000u);
+        if (s->start_id > 0) s->g_est[s->start_id] = 0;
+        s->pool.clear();
+    }
     const int32_t *ps, *pc;
     int cnt = 0;
-    if (int e = get_succs(s, id, &ps, &pc, &cnt)) return e;
+    if (int e = get_succs(s, id, &ps, &pc, &cnt)) {
+        // the SBPL-side caller (GetSuccs has no return value) sees an empty list; the error stays readable here
+        if (s->status == SMPLX_OK) { s->status = e; s->status_msg = g_error; }
+        return e;
+    }
     *n = cnt;
     for (int i = 0; i < cnt && i < cap; ++i) {
         if (succs) succs[i] = ps[i];
@@ -1936,6 +2107,7 @@ int smplx_post_process_path(smplx_space* s, const double* path, int n, int flags
                             int64_t* stats)
 {
     if (!s || (!path && n > 0) || n < 0 || !nout) return set_error(SMPLX_E_ARG, "bad argument");
+    if (n > 0 && !sane_values(path, (size_t)n * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     PathTools T(s);
     std::vector<double> p(path, path + (size_t)n * s->N);
     const bool fork_test = !(flags & SMPLX_PP_UPSTREAM_LIMITS);

@@ -60,6 +60,7 @@ __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const dou
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);
 __global__ void k_heuristic(const SmplxSpaceDev* S, const double* Q, int n, int* out_h, double* out_xyz);
 __global__ void k_sphere_positions(const SmplxSpaceDev* S, const double* Q, int n, double* out);
+__global__ void k_bfs_metric(SmplxGridDev grid, SmplxBfsDev bfs, const double* xyz, int n, double* out);
 __global__ void k_bfs_init(SmplxGridDev g, int wall_thr, int dim_x, int dim_y, int dim_z, int* dist);
 __global__ void k_bfs_reset(int* dist, size_t total);
 __global__ void k_bfs_seed(int* dist, int origin, int* queue, int* counts);

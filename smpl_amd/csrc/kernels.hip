@@ -1708,6 +1708,18 @@ k_heuristic(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, i
     if (out_xyz) { out_xyz[3 * i] = p[0]; out_xyz[3 * i + 1] = p[1]; out_xyz[3 * i + 2] = p[2]; }
 }
 
+// BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138) for a batch of workspace points
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_bfs_metric(SmplxGridDev grid, SmplxBfsDev bfs, const double* __restrict__ xyz, int n, double* __restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    int c[3];
+    world_to_cell(grid, p, c);
+    out[i] = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
+}
+
 // debug/parity: world positions of every tree node for one configuration per thread
 extern "C" __global__ void __launch_bounds__(BLOCK)
 k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, int n, double* __restrict__ out)

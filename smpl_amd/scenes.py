@@ -298,7 +298,9 @@ class PlanningParams:
     short_thresh: float = 0.4
     use_xyzrpy_snap: bool = True
     xyzrpy_thresh: float = 0.04
-    xy_rotate_by_var3: bool = False   # [FORK] switch; parity runs cover both
+    # [FORK] manip_lattice_action_space.cpp:590-599 rotates delta[0], delta[1] by state[3] in every
+    # applyMotionPrimitive: that is the reference's behaviour and the default here; False = upstream smpl
+    xy_rotate_by_var3: bool = True
     use_long_and_short: bool = False
     eps0: float = 5.0
     eps_final: float = 1.0
@@ -423,3 +425,43 @@ def random_states(cfg_limits, n: int, seed: int = 12345) -> np.ndarray:
 
 ARM7_LIMITS = [(-2.2, 0.7), (-0.5, 1.3), (-3.9, 0.8), (-2.3, 0.0), (-math.pi, math.pi), (-2.1, 0.0),
                (-math.pi, math.pi)]
+
+
+# ----------------------------------------------------------------------------
+# BASELINE config 4: 1024 independent (start, goal) queries on the config-2 scene, 128 per GPU
+# ----------------------------------------------------------------------------
+
+def config4_candidates(n: int = 1024, seed: int = 4, oversample: int = 3):
+    """Candidate (start, goal) pairs of SURVEY 8d cfg 4 (seed 4): whole-cell offsets from the cfg-2 start and goal
+    (1 degree cells; joints 4-6 in multiples of 4 cells, the short primitives' step).  Returns two arrays of
+    oversample*n rows; the caller keeps the first n pairs whose two ends its collision checker accepts
+    (config4_queries) -- the engine in bench.py and the tests, so that the list is a function of seed and scene only."""
+    rng = np.random.default_rng(seed)
+    m = n * oversample
+    ds = rng.integers(-20, 21, size=(m, 7))
+    dg = rng.integers(-12, 13, size=(m, 7))
+    ds[:, 4:] = 4 * rng.integers(-4, 5, size=(m, 3))
+    dg[:, 4:] = 4 * rng.integers(-3, 4, size=(m, 3))
+    starts = np.asarray(ARM7_START)[None, :] + ds * DEG
+    goals = np.asarray(_arm7_goal())[None, :] + dg * DEG
+    lo = np.array([l for (l, h) in ARM7_LIMITS]); hi = np.array([h for (l, h) in ARM7_LIMITS])
+    cont = np.array([False, False, False, False, True, False, True])
+    inside = lambda q: np.all((q >= lo) & (q <= hi) | cont, axis=1)   # noqa: E731
+    keep = inside(starts) & inside(goals)
+    return starts[keep], goals[keep]
+
+
+def config4_queries(starts, goals, start_ok, goal_ok, n: int = 1024):
+    """First n candidate pairs with both ends valid; query i belongs to rank i // 128 (SURVEY 8e)."""
+    ok = np.asarray(start_ok, bool) & np.asarray(goal_ok, bool)
+    idx = np.nonzero(ok)[0][:n]
+    if idx.shape[0] < n:
+        raise ValueError(f"only {idx.shape[0]} valid pairs among {ok.shape[0]} candidates")
+    return starts[idx], goals[idx]
+
+
+def shard_range(rank: int, world: int, total: int = 1024, per_rank: int = 128):
+    """Queries [first, last) of rank `rank`: 128 per GPU (BASELINE config 4); with fewer than total/per_rank ranks the
+    job simply covers a prefix of the list (weak scaling: per-GPU work is fixed)."""
+    first = rank * per_rank
+    return first, min(first + per_rank, total)

@@ -144,3 +144,13 @@ def test_per_robot_source_compiles_for_gfx950_with_the_helper(robot, tmp_path):
     for k in ("k_pipe_prep", "k_pipe_setup", "k_pipe_configs", "k_pipe_finish", "k_small_batch", "k_expand", "k_state_valid",
               "k_edge_valid", "k_heuristic", "k_sphere_positions", "k_state_prep"):
         assert k.encode() in code
+
+
+def test_default_is_the_forks_xy_rotation(small_cfg):
+    """[FORK] manip_lattice_action_space.cpp:590-599: delta[0], delta[1] rotated by state[3] -- the reference's
+    behaviour is what every config runs unless told otherwise (xy_rotate_by_var3 = 0 selects upstream smpl)."""
+    from smpl_amd import scenes
+    assert small_cfg.params.xy_rotate_by_var3 is True
+    assert scenes.PlanningParams([scenes.DEG] * 7).xy_rotate_by_var3 is True
+    for cfg in (scenes.config_mixed(n=16, nboxes=0),):
+        assert cfg.params.xy_rotate_by_var3 is True

@@ -1,0 +1,216 @@
+"""GPU parity at the BASELINE configs' own sizes: cfg 1 (128^3), cfg 2 (256^3, eps 5, B = 4096),
+cfg 4 (the 128-query shard of one GPU), cfg 5 (14-DOF, 512^3).  cfg 3 is in test_gpu_parity.py.  Everything
+through the C-ABI, against the oracle on the same seeded inputs; fork semantics (the default)."""
+import numpy as np
+import pytest
+
+from smpl_amd import scenes
+
+pytestmark = pytest.mark.gpu
+DEG = scenes.DEG
+
+
+def _need_gpu():
+    from smpl_amd import capi
+    if capi.lib().smplx_device_count() == 0:
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+
+
+def _compare_batch(o, s, Q):
+    got = s.expand_batch(Q)
+    for i, q in enumerate(Q):
+        e = o.eval_state(q)
+        assert np.array_equal(e["flags"], got["flags"][i]), f"flags of state {i}"
+        v = (e["flags"] & 1) != 0
+        ev = (e["flags"] & 0x10) == 0
+        assert np.array_equal(e["coord"][v], got["coord"][i][v])
+        assert np.array_equal(e["q"][ev], got["q"][i][ev])
+        assert np.array_equal(e["h"][v], got["h"][i][v]) and np.array_equal(e["cost"][v], got["cost"][i][v])
+        coll = (e["flags"] & 0x40) != 0
+        assert np.array_equal(e["lookups"][~coll], got["lookups"][i][~coll])
+    return got
+
+
+def _same_search(o, s, eps0, nb_init, nb_rep):
+    o.search_params(eps0, 1.0, 1.0, True, True, nb_init, nb_rep)
+    eo = o.plan()
+    go = s.plan(eps0, 1.0, 1.0, True, True, nb_init, nb_rep)
+    assert eo["ok"] == go["solved"] and eo["expansions"] == go["expansions"]
+    assert np.array_equal(eo["expansion_log"], go["expansion_log"])       # expanded-state set and order, ids bit-exact
+    assert eo["cost"] == go["cost"] and np.array_equal(eo["path"], go["path"])
+    assert eo["eps"] == go["satisfied_eps"]
+    assert o.num_states() == s.num_states()
+    assert eo["succ_evals"] == go["committed_succ_evals"]
+    return eo, go
+
+
+def test_config1_128cube_on_the_gpu():
+    """cfg 1's query (the CPU plumbing case) through the engine: same search as the oracle's."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = scenes.config1()
+    o = Oracle(cfg)
+    s = capi.Space.from_config(cfg, batch_states=1024)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+    assert o.set_start(cfg.start) == s.set_start(cfg.start) == 1
+    eo, go = _same_search(o, s, cfg.params.eps0, 4000, 4000)
+    assert go["solved"] == 1
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    return scenes.config2()
+
+
+def test_config2_256cube_bfs_frontier_batch_and_bounded_search(cfg2):
+    """cfg 2 at full size: BFS grid equality at 256^3, a B = 4096 frontier batch of real search states (the bench
+    step's input), and the bounded eps 5 -> 1 search of the bench's planner leg."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = cfg2
+    assert cfg.grid.dims == (256, 256, 256)
+    o = Oracle(cfg)
+    s = capi.Space.from_config(cfg, batch_states=4096)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert np.array_equal(o.goal_pose(), s.goal_pose())
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    eo, go = _same_search(o, s, cfg.params.eps0, 40000, 40000)
+    assert go["gpu_batches"] > 0 and go["gpu_succ_evals"] >= go["committed_succ_evals"]
+    # the frontier batch: the first 4096 states the search created, evaluated in one call; a sample of rows against the
+    # oracle (its per-state evaluation is the slow side), every row against a second, smaller-batch evaluation
+    Q = np.stack([s.get_state(i)[0] for i in range(1, 4097)])
+    o.set_order(chain=True)
+    got = s.expand_batch(Q)
+    rows = np.r_[0:64, 2000:2064, 4032:4096]
+    sub = _compare_batch(o, s, Q[rows])
+    for k in ("flags", "coord", "q", "h", "cost"):
+        assert np.array_equal(sub[k], got[k][rows])
+    again = np.concatenate([s.expand_batch(Q[i:i + 512])["flags"] for i in range(0, 4096, 512)])
+    assert np.array_equal(again, got["flags"])
+
+
+def test_config4_shard_128_queries_on_one_gpu(cfg2):
+    """The per-GPU shard of cfg 4: 128 independent (start, goal) queries of the seeded list on ONE shared grid and model
+    through smplx_plan_multi.  Every query equals its solo GPU run; a sample of 8 equals the oracle."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = cfg2
+    grid = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
+    model = capi.Model(cfg.robot_text)
+    probe = capi.Space(model, grid, cfg.mprim, cfg.params, 256)
+    cs, cg = scenes.config4_candidates()
+    S, G = scenes.config4_queries(cs, cg, probe.state_valid_batch(cs)[0], probe.state_valid_batch(cg)[0])
+    first, last = scenes.shard_range(0, 8)
+    S, G = S[first:last], G[first:last]
+    assert S.shape == (128, 7)
+    nb = 1500
+    spaces = []
+    for a, b in zip(S, G):
+        sp = capi.Space(model, grid, cfg.mprim, cfg.params, 1024)
+        sp.set_goal_joint(b, cfg.goal_tol)
+        sp.set_start(a)
+        spaces.append(sp)
+    multi, wall = capi.Space.plan_multi(spaces, 5.0, 1.0, 1.0, True, True, nb, nb, host_threads=4)
+    assert len(multi) == 128 and wall > 0
+    # solo runs of every query on a fresh space (one at a time: its own batches on its own stream)
+    for i, (a, b) in enumerate(zip(S, G)):
+        probe.set_goal_joint(b, cfg.goal_tol)
+        probe.set_start(a)
+        solo = probe.plan(5.0, 1.0, 1.0, True, True, nb, nb)
+        m = multi[i]
+        assert solo["solved"] == m["solved"] and solo["cost"] == m["cost"] and solo["expansions"] == m["expansions"], i
+        assert np.array_equal(solo["expansion_log"], m["expansion_log"]), i
+        assert np.array_equal(solo["path"], m["path"]), i
+    for i in range(0, 128, 16):
+        o = Oracle(cfg)
+        o.set_goal_joint(G[i], cfg.goal_tol)
+        o.set_start(S[i])
+        o.search_params(5.0, 1.0, 1.0, True, True, nb, nb)
+        e = o.plan()
+        m = multi[i]
+        assert e["ok"] == m["solved"] and e["cost"] == m["cost"] and np.array_equal(e["expansion_log"], m["expansion_log"]), i
+    assert sum(m["expansions"] for m in multi) > 100 * nb
+
+
+def test_config5_dual_arm_512cube():
+    """cfg 5 at full size: 14-DOF dual arm, 512^3 grid @ 0.01 m, 59 primitives, 85 checked link pairs: BFS grid,
+    a 64-state expansion batch and a bounded eps 10 -> 1 search, all identical to the oracle."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = scenes.config5()
+    assert cfg.grid.dims == (512, 512, 512) and cfg.grid.res == 0.01
+    s = capi.Space.from_config(cfg, batch_states=4096)
+    assert (s.model.nvars, s.model.ntrees, s.model.npairs, s.M) == (14, 16, 85, 59)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+    lim = scenes.ARM7_LIMITS + scenes.ARM7_LIMITS
+    Q = np.vstack([np.array(cfg.start), scenes.random_states(lim, 63, 77)])
+    got = _compare_batch(o, s, Q)
+    assert (got["flags"] & 1).sum() > 50
+    o.set_order(chain=False)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    _same_search(o, s, cfg.params.eps0, 3000, 3000)
+
+
+def test_strictly_growing_and_shrinking_batches_on_one_space(small_cfg):
+    """Regression for the k_pipe_configs memory fault of round 1: one space, the four-kernel
+    pipeline forced for every size, batches that grow past every earlier reservation (buffers are re-allocated and
+    re-carved) and shrink again; each batch compared with the oracle row by row."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg, no_small_kernel=True)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    Q = scenes.random_states(scenes.ARM7_LIMITS, 1200, 91)
+    ref = {}
+    for B in [1, 2, 3, 7, 64, 65, 129, 300, 777, 1200, 5, 640, 1, 1200]:
+        got = s.expand_batch(Q[:B])
+        for i in range(0, B, max(1, B // 24)):
+            if i not in ref:
+                ref[i] = o.eval_state(Q[i])
+            e = ref[i]
+            assert np.array_equal(e["flags"], got["flags"][i]), (B, i)
+            v = (e["flags"] & 1) != 0
+            assert np.array_equal(e["coord"][v], got["coord"][i][v]) and np.array_equal(e["h"][v], got["h"][i][v])
+    # the same through the planner (its batch sizes follow OPEN: 1, 2, ... up to batch_states) with the pipeline forced
+    for bs in (7, 64, 1024):
+        sp = capi.Space.from_config(cfg, batch_states=bs, no_small_kernel=True)
+        sp.set_goal_joint(cfg.goal, cfg.goal_tol)
+        sp.set_start(cfg.start)
+        oo = Oracle(cfg)
+        oo.set_goal_joint(cfg.goal, cfg.goal_tol)
+        oo.set_start(cfg.start)
+        oo.search_params(5.0, 1.0, 1.0, True, True, 2000, 2000)
+        e = oo.plan()
+        g = sp.plan(5.0, 1.0, 1.0, True, True, 2000, 2000)
+        assert e["cost"] == g["cost"] and np.array_equal(e["expansion_log"], g["expansion_log"]), bs
+
+
+def test_non_finite_and_absurd_inputs_are_refused(small_cfg):
+    """A NaN / inf / 1e300 joint value must come back as SMPLX_E_ARG, not reach the device (the reference's limit
+    folding, kdl_robot_model.cpp:210-235, would not terminate on it)."""
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    s = capi.Space.from_config(cfg)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    for bad in (np.nan, np.inf, -np.inf, 1e300):
+        q = np.array([cfg.start, cfg.start]); q[1, 2] = bad
+        for call in (lambda: s.state_valid_batch(q), lambda: s.edge_valid_batch(q, q), lambda: s.expand_batch(q),
+                     lambda: s.heuristic_batch(q), lambda: s.set_start(q[1]), lambda: s.sphere_positions(q)):
+            with pytest.raises(capi.SmplxError) as err:
+                call()
+            assert err.value.code == -1
+    assert s.state_valid_batch(np.array([cfg.start]))[0][0] == 1      # the space is still usable

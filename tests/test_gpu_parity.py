@@ -149,12 +149,13 @@ def test_expand_batch_near_goal_and_start(ctx):
     assert (got["flags"] & 2).sum() >= 7   # goal successors (short primitive back, or the snap)
 
 
-def test_expand_batch_fork_xy_rotation(small_cfg):
+def test_expand_batch_upstream_semantics_switch(small_cfg):
+    """xy_rotate_by_var3 = 0: upstream smpl's applyMotionPrimitive (no rotation), kept as an opt-out."""
     from oracle_binding import Oracle
     from smpl_amd import capi
-    o = Oracle(small_cfg, xy_rotate=True)
+    o = Oracle(small_cfg, xy_rotate=False)
     o.set_order(chain=True)
-    s = capi.Space.from_config(small_cfg, xy_rotate=True)
+    s = capi.Space.from_config(small_cfg, xy_rotate=False)
     s.fused = False
     o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
     s.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
@@ -181,14 +182,17 @@ def test_getsuccs_ids_match_sequential_reference_order(ctx):
         assert o.heuristic_q(eq) == s.goal_heuristic(i)
 
 
+@pytest.mark.parametrize("semantics", ["fork", "upstream"])
 @pytest.mark.parametrize("fused", [False, True, "pipeline-only"])
 @pytest.mark.parametrize("goal_kind", ["joint", "xyz"])
-def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused):
+def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused, semantics):
     from oracle_binding import Oracle
     from smpl_amd import capi
     cfg = small_cfg
-    o = Oracle(cfg)
-    s = capi.Space.from_config(cfg, batch_states=256, fused=(fused is True), no_small_kernel=(fused == "pipeline-only"))
+    rot = semantics == "fork"
+    o = Oracle(cfg, xy_rotate=rot)
+    s = capi.Space.from_config(cfg, batch_states=256, xy_rotate=rot, fused=(fused is True),
+                               no_small_kernel=(fused == "pipeline-only"))
     if goal_kind == "joint":
         o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
     else:

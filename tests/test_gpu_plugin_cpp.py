@@ -1,5 +1,6 @@
 """The C++ plugin mirror (include/smpl_amd/plugin.hpp) driven like smpl drives its plugins, on the GPU,
-compared line by line with the oracle."""
+compared line by line with the oracle: once call by call (plugin_driver.cpp), once by an SBPL-shaped ARA* loop
+that knows only GetSuccs / GetGoalHeuristic (sbpl_loop_driver.cpp)."""
 import os
 import subprocess
 
@@ -10,26 +11,38 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_plugin_driver_matches_oracle(small_cfg, tmp_path):
-    from oracle_binding import Oracle
+def build_driver(name, out_dir):
     from smpl_amd import build
-    cfg = small_cfg
     lib = build.build()
-    exe = tmp_path / "plugin_driver"
+    exe = os.path.join(str(out_dir), name)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "plugin_driver.cpp"), "-o", str(exe),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            lib, f"-Wl,-rpath,{os.path.dirname(lib)}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
                            "-lamdhip64"])
-    (tmp_path / "robot.txt").write_text(cfg.robot_text)
-    (tmp_path / "mprim.txt").write_text(cfg.mprim)
-    np.ascontiguousarray(cfg.grid.d2, np.int32).tofile(tmp_path / "grid.bin")
+    return exe
+
+
+def write_query(cfg, out_dir, tail):
+    """robot.txt, mprim.txt, grid.bin and query.txt (scene + params + start + goal + tolerances + `tail`)."""
+    out_dir = str(out_dir)
+    open(os.path.join(out_dir, "robot.txt"), "w").write(cfg.robot_text)
+    open(os.path.join(out_dir, "mprim.txt"), "w").write(cfg.mprim)
+    np.ascontiguousarray(cfg.grid.d2, np.int32).tofile(os.path.join(out_dir, "grid.bin"))
     p, g = cfg.params, cfg.grid
+    fields = [*g.origin, *g.dims, g.res, g.max_dist, len(cfg.start), *p.resolutions, p.bfs_radius, p.cost_per_cell,
+              int(p.use_short), p.short_thresh, int(p.use_xyzrpy_snap), p.xyzrpy_thresh, int(p.xy_rotate_by_var3),
+              int(p.use_long_and_short), *cfg.start, *cfg.goal, *cfg.goal_tol, *tail]
+    open(os.path.join(out_dir, "query.txt"), "w").write(
+        " ".join(repr(float(x)) if isinstance(x, float) else str(x) for x in fields))
+
+
+def test_cpp_plugin_driver_matches_oracle(small_cfg, tmp_path):
+    from oracle_binding import Oracle
+    cfg = small_cfg
+    exe = build_driver("plugin_driver", tmp_path)
     nexp = 25
-    fields = [*g.origin, *g.dims, g.res, g.max_dist, 7, *p.resolutions, p.bfs_radius, p.cost_per_cell, int(p.use_short),
-              p.short_thresh, int(p.use_xyzrpy_snap), p.xyzrpy_thresh, int(p.xy_rotate_by_var3), int(p.use_long_and_short),
-              *cfg.start, *cfg.goal, *cfg.goal_tol, nexp]
-    (tmp_path / "query.txt").write_text(" ".join(repr(float(x)) if isinstance(x, float) else str(x) for x in fields))
-    out = subprocess.run([str(exe), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    write_query(cfg, tmp_path, [nexp])
+    out = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = out.stdout.decode().splitlines()
     o = Oracle(cfg)
@@ -59,3 +72,36 @@ def test_cpp_plugin_driver_matches_oracle(small_cfg, tmp_path):
         assert lines[k] == exp
         k += 1
     assert lines[k] == "done"
+
+
+@pytest.mark.parametrize("eps0,bound", [(5.0, (6000, 3000)), (2.0, (2500, 2500))])
+def test_sbpl_shaped_arastar_loop_over_the_plugin_mirror(small_cfg, tmp_path, eps0, bound):
+    """An ARA* that only knows RobotPlanningSpace::GetSuccs / GetGoalHeuristic (what smpl's unchanged ARAStar knows),
+    wired like PlannerInterface wires its plugins (init, insertHeuristic, setGoal(GoalConstraint), setStart): expansion
+    log, path and cost equal the oracle's; the metric distances come from the RobotHeuristic virtuals."""
+    from oracle_binding import Oracle
+    cfg = small_cfg
+    exe = build_driver("sbpl_loop_driver", tmp_path)
+    write_query(cfg, tmp_path, [eps0, 1.0, 1.0, bound[0], bound[1]])
+    out = subprocess.run([exe, str(tmp_path), "log"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = {l.split(" ", 1)[0]: l.split(" ", 1)[1] if " " in l else "" for l in out.stdout.decode().splitlines()}
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    o.set_start(cfg.start)
+    o.search_params(eps0, 1.0, 1.0, True, True, bound[0], bound[1])
+    e = o.plan()
+    solved, cost, nexp, plen, secs, eps = lines["result"].split()
+    assert int(solved) == e["ok"] and int(nexp) == e["expansions"]
+    assert np.array_equal(np.array(lines["log"].split(), dtype=np.int64), e["expansion_log"])
+    if e["ok"]:
+        assert int(cost) == e["cost"] and float(eps) == e["eps"]
+        assert np.array_equal(np.array(lines["path"].split(), dtype=np.int64), e["path"])
+    # getMetricGoalDistance at the goal pose is 0 (the seeded BFS cell); getMetricStartDistance is the Manhattan
+    # cell distance to the start's planning link times the resolution (bfs_heuristic.cpp:103-138)
+    gp = o.goal_pose()
+    mg, ms = [float(x) for x in lines["metric"].split()]
+    assert mg == o.metric_goal_distance(*gp) == 0.0
+    cs, cg = o.world_to_grid(*o.planning_fk(cfg.start)), o.world_to_grid(*gp)
+    assert ms == cfg.grid.res * float(np.abs(cs.astype(np.int64) - cg).sum())
+    assert "done" in lines
