@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- successor evaluations/s of the ARA* state-expansion hot path on MI355X.
+"""bench.py -- the ARA* state-expansion hot path of smpl on MI355X: successor evaluations/s and states expanded/s.
 
-A "step" is one frontier-batched expansion: B = 4096 open states of a real ARA* search on the
-config-2 scene (7-DOF arm, 256^3 voxel grid @ 0.02 m, tabletop + 64 seeded boxes), every motion
-primitive applied to every state (k_state_prep + k_expand), inputs and outputs resident in HBM.
-`value` = successor evaluations (state x active primitive, the loop body of
-smpl/src/graph/manip_lattice.cpp:263-305) per second, whole job.
+`value` (BASELINE.json metric, config 2): one STEP = one frontier-batched expansion, B = 4096 open states of a real
+ARA* search on the config-2 scene (7-DOF arm, 256^3 voxel grid @ 0.02 m, tabletop + 64 seeded boxes), every motion
+primitive applied to every state -- the loop body of ManipLattice::GetSuccs (smpl/src/graph/manip_lattice.cpp:263-305)
+for every (state, primitive) -- inputs and outputs resident in HBM.  value = successor evaluations / s, whole job.
 
-N > 1 (driver: torch.distributed.run, one rank per GPU, RCCL): the batched-query shard of
-BASELINE config 4 -- every rank owns an independent query (its own goal, BFS grid, state table and
-frontier) on the replicated scene, no collective on the data path; per-rank result records are
-all-gathered at the end.  Weak scaling.
+That figure is a kernel-level rate.  What a caller of the plugin API gets is reported beside it, in the same line:
+  planner        one query through smplx_plan (the engine's own ARA*, frontier hints from its OPEN list)
+  planner_plain  the same query driven by an SBPL-shaped ARA* that only knows GetSuccs / GetGoalHeuristic
+                 (tests/cpp/sbpl_loop_driver.cpp over include/smpl_amd/plugin.hpp; no hints)
+  shard          BASELINE config 4's per-GPU shard: 128 independent queries of the seeded list through
+                 smplx_plan_multi -- states expanded/s and successor evaluations/s (committed and total)
+  cpu_baseline   the oracle (CPU restatement) on one host core over the step's batch; cpu_shard: the same queries as
+                 `shard`, one per host thread, on the oracle
+  k2             the collision micro-benchmark SURVEY 8(d) states the 60 % roofline target on: 2^20 configurations
+                 q ~ U[limits], std::mt19937_64 seed 12345 (benchmark_cc.cpp:280-301), through the state-validity kernel
 
-Extra objects on the JSON line: `roofline` (k_expand, HIP events on the launch stream inside the
-timed region), `cpu_baseline` (the oracle, one host thread, rank 0 at N=1) and `planner`
-(states expanded/s of a bounded ARA* query, GPU engine vs oracle, with the parity bits).
+N > 1 (driver: torch.distributed.run, one rank per GPU, RCCL): queries shard by rank -- rank r owns queries
+[128 r, 128 r + 128) of the seeded config-4 list on the replicated scene (its own goals, BFS grids, state tables), no
+collective on the data path; the per-query result records are all-gathered once at the end (smpl_amd/shard.py).  Every
+rank times the step on a frontier of its own first query and runs its shard; `value` = step evaluations of all ranks /
+max-over-ranks time (weak scaling), `shard` = whole-job figures of the config-4 run.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -32,30 +42,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def rank_goal_shift(rank: int):
-    """Goal offset (whole lattice cells) of rank r's query: independent queries on the replicated scene.
-    Joints 4-6 move in multiples of 4 cells so the goal stays on the lattice the short primitives reach."""
-    if rank == 0:
-        return [0] * 7
-    return [(-3 * rank) % 17 - 8, (2 * rank) % 9 - 4, (5 * rank) % 13 - 6, (-rank) % 7 - 3, 4 * (rank % 5 - 2),
-            4 * (rank % 3 - 1), 4 * (rank % 7 - 3)]
+def host_threads_available(cap: int) -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))
 
 
-def gather_records(rec, dist, world):
-    """All-gather of the per-rank result record (RCCL on GPUs, gloo in the CPU test); the only collective."""
-    import torch
-    if dist is None or world == 1:
-        return rec.detach().cpu().numpy()[None]
-    allrec = [torch.zeros_like(rec) for _ in range(world)]
-    dist.all_gather(allrec, rec)
-    return torch.stack(allrec).cpu().numpy()
-
-
-def aggregate(allrec):
-    """Whole-job throughput: units of all ranks / max-over-ranks time."""
-    total = float(allrec[:, 0].sum())
-    tmax = float(allrec[:, 1].max())
-    return total / tmax, tmax, total
+def frontier_of(space, B, p, nwarm0):
+    """The first B states a bounded search creates (a real frontier, not random states)."""
+    nw = nwarm0
+    while space.num_states() <= B and nw <= 16 * max(B, nwarm0):
+        space.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nw, nw)
+        nw *= 2
+    if space.num_states() <= B:
+        return None
+    return np.stack([space.get_state(i)[0] for i in range(1, B + 1)])
 
 
 def main():
@@ -66,17 +69,22 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_shard leg (the box's CPU share)")
     ap.add_argument("--planner-expansions", type=int, default=40000)
-    ap.add_argument("--multi-queries", type=int, default=32, help="queries interleaved on one GPU in the planner leg")
-    ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the planner_multi leg")
+    ap.add_argument("--queries-per-gpu", type=int, default=128, help="config-4 shard size per rank")
+    ap.add_argument("--shard-expansions", type=int, default=20000, help="expansion bound per query in the shard leg")
+    ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the shard leg")
     ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="timed steps whose kernels are bracketed by HIP events (default: steps/8, at least 1); every "
                          "event costs the stream a marker, about 3 us, three of them per profiled step")
     ap.add_argument("--scaling-batches", type=str, default="16384,65536",
                     help="secondary figure: the same step at larger frontier batches (comma list, empty to skip)")
+    ap.add_argument("--k2-states", type=int, default=1 << 20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
+    ap.add_argument("--no-shard", action="store_true")
+    ap.add_argument("--no-k2", action="store_true")
     ap.add_argument("--generic-kernels", action="store_true", help="skip the per-robot hiprtc build (A/B runs)")
     args = ap.parse_args()
 
@@ -93,32 +101,41 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
 
-    from smpl_amd import capi, scenes
+    from smpl_amd import capi, scenes, shard
 
-    # ---- inputs: config-2 scene; every rank its own query on the replicated scene ----
+    # ---- the replicated scene and this rank's queries ---------------------------------------------------------------
     cfg = scenes.config2(n=args.grid)
-    goal = list(cfg.goal)
-    if rank > 0:   # independent queries: shift the goal by whole lattice cells, keep it reachable
-        goal = [g + c * scenes.DEG for g, c in zip(goal, rank_goal_shift(rank))]
-    space = capi.Space.from_config(cfg, batch_states=args.batch, generic_kernels=args.generic_kernels)
-    spec_ok, spec_note = space.specialized()
-    ok, _ = space.state_valid_batch(np.array([goal]))
-    if not ok[0]:
-        goal = list(cfg.goal)
-    space.set_goal_joint(goal, cfg.goal_tol)
-    space.set_start(cfg.start)
-    # a real frontier: run the search far enough to own >= B states, take the first B created
     p = cfg.params
+    grid_h = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
+    model_h = capi.Model(cfg.robot_text)
+
+    def new_space(batch=args.batch):
+        return capi.Space(model_h, grid_h, cfg.mprim, p, batch, generic_kernels=args.generic_kernels)
+
+    space = new_space()
+    spec_ok, spec_note = space.specialized()
+    # BASELINE config 4: the seeded list of (start, goal) pairs; validity of the candidates decided by the engine
+    cs, cg = scenes.config4_candidates()
+    S_all, G_all = scenes.config4_queries(cs, cg, space.state_valid_batch(cs)[0], space.state_valid_batch(cg)[0])
+    first, last, S_mine, G_mine = shard.rank_queries(S_all, G_all, rank, world, args.queries_per_gpu)
+
+    # ---- the step: a frontier batch of this rank's own query (rank 0: the config-2 query itself) -------------------
     B = args.batch
-    nwarm = max(1500, B // 3)
-    warm = space.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nwarm, nwarm)
-    if space.num_states() <= B:
+    q_start, q_goal = (list(cfg.start), list(cfg.goal)) if rank == 0 or len(S_mine) == 0 else (S_mine[0], G_mine[0])
+    space.set_goal_joint(q_goal, cfg.goal_tol)
+    space.set_start(q_start)
+    Q = frontier_of(space, B, p, max(1500, B // 3))
+    if Q is None:   # that query ends before it owns B states: take the config-2 query's frontier
+        q_start, q_goal = list(cfg.start), list(cfg.goal)
+        space.set_goal_joint(q_goal, cfg.goal_tol)
+        space.set_start(q_start)
+        Q = frontier_of(space, B, p, max(1500, B // 3))
+    if Q is None:
         raise SystemExit(f"search produced only {space.num_states()} states, need {B}")
-    Q = np.stack([space.get_state(i)[0] for i in range(1, B + 1)])
     N, M = space.N, space.M
 
-    dev = torch.device("cuda", local_rank)
     d_q = torch.from_numpy(Q).to(dev)
     d_flags = torch.zeros(B * M, dtype=torch.uint8, device=dev)
     d_coord = torch.zeros(B * M * N, dtype=torch.int32, device=dev)
@@ -154,12 +171,11 @@ def main():
     evals, valid, lookups_ref, lookups_done, configs, state_lookups = space.counters_read(d_cnt.data_ptr(), B)
     elapsed = t1 - t0
 
-    # ---- whole-job aggregate: max time over ranks, sum of units ----
-    rec = torch.tensor([float(evals), elapsed, float(valid)], dtype=torch.float64, device=dev)
-    allrec = gather_records(rec, dist, world)   # RCCL all-gather of the per-rank result records
-    value, tmax, total_evals = aggregate(allrec)
+    # whole-job aggregate: units of all ranks / max-over-ranks time (one all-gather of three doubles per rank)
+    sc = shard.gather_scalars([float(evals), elapsed, float(valid)], dist, world, dev)
+    value, tmax, total_evals = shard.aggregate(sc[:, :2])
 
-    # ---- roofline of the dominant kernel (k_pipe_configs: the collision check), this rank ----
+    # ---- roofline of the dominant kernel (k_pipe_configs: the collision check), this rank ---------------------------
     # SURVEY 8(d), collision kernel: algorithmic bytes = 4 B per distance-grid lookup + 8N B per configuration.
     # HIP events on the launch stream bracket the kernel inside the timed region (smplx_profile_*).
     L_ = max(args.steps, 1)        # the tallies cover every timed step
@@ -191,15 +207,19 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"cfg2: 7-DOF arm7, {args.grid}^3 grid @ 0.02 m, tabletop + 64 boxes (seed 2), "
-                               f"frontier batch B={B} open states x M={M} primitives, eps 5 ARA* frontier",
+                               f"frontier batch B={B} open states x M={M} primitives, eps 5 ARA* frontier; fork "
+                               f"semantics (xy rotation by state[3])",
                    "batch_states": B, "primitives": M, "grid": args.grid, "queries": world,
-                   "parallelism": f"query-shard x{world}" if world > 1 else "single query"},
+                   "parallelism": f"query-shard x{world} (cfg 4 list, 128 queries per GPU)" if world > 1 else "single query"},
+        "value_is": "kernel-level rate of the batched step (inputs resident in HBM); rates through the plugin API are in "
+                    "planner / planner_plain / shard",
         "valid_fraction": round(valid / max(evals, 1), 4),
         "kernels": ("per-robot hiprtc build, " + spec_note[:120]) if spec_ok else "generic (" + spec_note[:200] + ")",
         "roofline": roofline,
     }
+    single = rank == 0 and world == 1
 
-    if rank == 0 and world == 1 and args.overlap_streams > 1:
+    if single and args.overlap_streams > 1:
         # secondary figure: the same step with several independent frontier batches in flight (what a GPU that
         # serves many queries sees); each in-flight batch has its own buffers and stream.  Not `value`.
         S_ = args.overlap_streams
@@ -226,22 +246,19 @@ def main():
         t1o = time.perf_counter()
         out["overlapped"] = {"streams": S_, "steps": nst, "ms_per_step": round(1e3 * (t1o - t0o) / nst, 4),
                              "successor_evaluations_per_s": round(evals / max(args.steps, 1) * nst / (t1o - t0o), 1)}
+        del sets, streams
 
-    if rank == 0 and world == 1 and args.scaling_batches:
+    if single and args.scaling_batches:
         # secondary figure: the step at larger frontier batches (the kernels are latency-bound at B=4096: about two
         # waves per SIMD).  Same scene and query; the frontier is the first B2 states a longer search creates.  Not `value`.
         out["batch_scaling"] = {}
         for B2 in [int(x) for x in args.scaling_batches.split(",") if x]:
-            sp = capi.Space.from_config(cfg, batch_states=4096, generic_kernels=args.generic_kernels)
-            sp.set_goal_joint(goal, cfg.goal_tol)
-            sp.set_start(cfg.start)
-            nw = max(1500, B2 // 3)
-            while sp.num_states() <= B2 and nw <= 4 * B2:
-                sp.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nw, nw)
-                nw *= 2
-            if sp.num_states() <= B2:
+            sp = new_space(4096)
+            sp.set_goal_joint(q_goal, cfg.goal_tol)
+            sp.set_start(q_start)
+            Q2 = frontier_of(sp, B2, p, max(1500, B2 // 3))
+            if Q2 is None:
                 continue
-            Q2 = np.stack([sp.get_state(i)[0] for i in range(1, B2 + 1)])
             t = {k: torch.zeros(B2 * M * w, dtype=dt, device=dev) for k, w, dt in
                  [("flags", 1, torch.uint8), ("coord", N, torch.int32), ("sq", N, torch.float64), ("h", 1, torch.int32),
                   ("cost", 1, torch.int32), ("lk", 1, torch.int32)]}
@@ -268,41 +285,91 @@ def main():
                                              "successor_evaluations_per_s": round(ev2 / (tb - ta), 1)}
             del sp, t, q2, w2, c2
 
-    if rank == 0 and world == 1 and not args.no_cpu:
+    Oracle = None
+    if single and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_binding import Oracle
+        from oracle_binding import Oracle   # the checker; here only as the timed CPU baseline and the parity bits
+
+    if single and not args.no_k2:
+        # ---- K2: the collision micro-benchmark: 2^20 random configurations through the validity kernel ----
+        n2 = args.k2_states
+        Qk = scenes.benchmark_states(scenes.ARM7_LIMITS, n2, 12345)
+        dq = torch.from_numpy(Qk).to(dev)
+        dv = torch.zeros(n2, dtype=torch.uint8, device=dev)
+        dl = torch.zeros(n2, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            space.state_valid_batch_device(dq.data_ptr(), n2, dv.data_ptr(), dl.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            space.state_valid_batch_device(dq.data_ptr(), n2, dv.data_ptr(), dl.data_ptr(), stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        lk_total = int(dl.sum(dtype=torch.int64).item())
+        nvalid = int(dv.sum(dtype=torch.int64).item())
+        k2_bytes = 4.0 * lk_total + 8.0 * N * n2
+        k2 = {"kernel": "k_state_valid", "configs": n2, "inputs": "q ~ U[limits], std::mt19937_64 seed 12345 (benchmark_cc.cpp:280-301 scheme)",
+              "kernel_ms": round(ms, 4), "collision_checks_per_s": round(n2 / (ms * 1e-3), 1), "valid_fraction": round(nvalid / n2, 4),
+              "lookups": lk_total, "algorithmic_bytes": int(k2_bytes),
+              "roofline": {"bound": "hbm", "achieved": round(k2_bytes / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(k2_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}}
+        if Oracle is not None:
+            o = Oracle(cfg)
+            o.set_order(chain=True)
+            ns = min(n2, 200000)
+            ok_c, lk_c, sec = o.state_valid_batch_timed(Qk[:ns])
+            k2["cpu_checks_per_s_one_core"] = round(ns / sec, 1)
+            k2["cpu_sample"] = f"first {ns} of the same states, oracle, 1 thread ({sec:.1f} s)"
+            k2["parity"] = {"valid_bits_equal": bool(np.array_equal(ok_c, dv[:ns].cpu().numpy())),
+                            "lookups_equal_on_valid": bool(np.array_equal(lk_c[ok_c == 1], dl[:ns].cpu().numpy()[ok_c == 1]))}
+            del o
+        out["k2"] = k2
+        del dq, dv, dl
+
+    if single and Oracle is not None:
         o = Oracle(cfg)
-        o.set_goal_joint(goal, cfg.goal_tol)
+        o.set_goal_joint(q_goal, cfg.goal_tol)
         r = o.eval_batch_timed(Q, args.cpu_seconds)
         cpu_rate = r["evals"] / r["seconds"]
         out["cpu_baseline"] = {"value": round(cpu_rate, 1), "unit": "successor evaluations/s", "cores": 1, "kind": "port",
                                "sample": f"{r['passes']} pass(es) over the same {B}-state frontier batch "
                                          f"({r['evals']} evaluations, {r['seconds']:.1f} s), oracle/ C++ -O2, 1 thread, "
                                          f"logging/visualisation off, 4-byte cells; host has {os.cpu_count()} cores"}
-        if not args.no_planner:
-            nb = args.planner_expansions
+        del o
+
+    if single and not args.no_planner:
+        # ---- one query through the plugin API: smplx_plan (hints from the engine's own OPEN) ------------------------
+        nb = args.planner_expansions
+        sp2 = new_space()
+        sp2.set_goal_joint(q_goal, cfg.goal_tol)
+        sp2.set_start(q_start)
+        rg = sp2.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+        out["planner"] = {
+            "query": "cfg2 single query, ARA* eps 5->1 step 1, expansion bound %d, smplx_plan" % nb,
+            "gpu_states_expanded_per_s": round(rg["expansions"] / rg["seconds"], 1),
+            "succ_evals_per_s_committed": round(rg["committed_succ_evals"] / rg["seconds"], 1),
+            "succ_evals_per_s_gpu_total": round(rg["gpu_succ_evals"] / rg["seconds"], 1),
+            "expansions": rg["expansions"], "path_cost": rg["cost"], "satisfied_eps": rg["satisfied_eps"],
+            "gpu_seconds": round(rg["seconds"], 4),
+            "gpu_succ_evals_total": rg["gpu_succ_evals"], "committed_succ_evals": rg["committed_succ_evals"],
+            "gpu_batches": rg["gpu_batches"], "cache_hits": rg["cache_hits"], "cache_misses": rg["cache_misses"]}
+        if Oracle is not None:
             o2 = Oracle(cfg)
-            o2.set_goal_joint(goal, cfg.goal_tol)
-            o2.set_start(cfg.start)
+            o2.set_goal_joint(q_goal, cfg.goal_tol)
+            o2.set_start(q_start)
             o2.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
             ro = o2.plan()
-            sp2 = capi.Space.from_config(cfg, batch_states=args.batch, generic_kernels=args.generic_kernels)
-            sp2.set_goal_joint(goal, cfg.goal_tol)
-            sp2.set_start(cfg.start)
-            rg = sp2.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
-            out["planner"] = {
-                "query": "cfg2 single query, ARA* eps 5->1 step 1, expansion bound %d" % nb,
-                "gpu_states_expanded_per_s": round(rg["expansions"] / rg["seconds"], 1),
-                "cpu_states_expanded_per_s": round(ro["expansions"] / ro["seconds"], 1),
-                "expansions": rg["expansions"], "path_cost": rg["cost"], "satisfied_eps": rg["satisfied_eps"],
-                "gpu_seconds": round(rg["seconds"], 4), "cpu_seconds": round(ro["seconds"], 4),
-                "gpu_succ_evals_total": rg["gpu_succ_evals"], "committed_succ_evals": rg["committed_succ_evals"],
-                "speculative_succ_evals": rg["gpu_succ_evals"] - rg["committed_succ_evals"],
-                "gpu_batches": rg["gpu_batches"], "cache_hits": rg["cache_hits"], "cache_misses": rg["cache_misses"],
+            out["planner"].update({
+                "cpu_states_expanded_per_s": round(ro["expansions"] / ro["seconds"], 1), "cpu_seconds": round(ro["seconds"], 4),
+                "cpu_succ_evals_per_s": round(ro["succ_evals"] / ro["seconds"], 1),
                 "parity": {"cost_equal": bool(ro["cost"] == rg["cost"]),
                            "expansions_equal": bool(ro["expansions"] == rg["expansions"]),
                            "expanded_ids_equal": bool(np.array_equal(ro["expansion_log"], rg["expansion_log"])),
-                           "path_equal": bool(np.array_equal(ro["path"], rg["path"]))}}
+                           "path_equal": bool(np.array_equal(ro["path"], rg["path"])),
+                           "succ_evals_equal": bool(ro["succ_evals"] == rg["committed_succ_evals"])}})
             if rg["solved"]:
                 # row N3: postProcessPath (interpolate -> shortcut -> interpolate) of the found path, upstream limit
                 # test so that the interpolation passes do their work; GPU entry point vs the oracle's loops
@@ -313,42 +380,117 @@ def main():
                     got, st = sp2.post_process_path(P, True, True, True)
                 tg = (time.perf_counter() - t0) / 5
                 t0 = time.perf_counter()
-                want, ec, sc = o2.post_process(P, True, True, True)
+                want, ec, sc_ = o2.post_process(P, True, True, True)
                 tc = time.perf_counter() - t0
                 out["planner"]["post_process"] = {
                     "points_in": int(len(P)), "points_out": int(len(got)), "gpu_ms": round(tg * 1e3, 3),
                     "cpu_ms": round(tc * 1e3, 3), "gpu_configs_checked": int(st["configs"]),
-                    "gpu_batches": int(st["edge_batches"]), "cpu_edge_checks": int(ec), "cpu_state_checks": int(sc),
+                    "gpu_batches": int(st["edge_batches"]), "cpu_edge_checks": int(ec), "cpu_state_checks": int(sc_),
                     "equal": bool(got.shape == want.shape and np.array_equal(got, want))}
+            del o2
+        del sp2
 
-    if rank == 0 and world == 1 and not args.no_planner and args.multi_queries > 1:
-        # batched-query planner leg (BASELINE config 4 shape on one GPU): Q independent queries interleaved by one
-        # host thread; aggregate committed expansions / wall time.  Parity is checked on the first query when the
-        # CPU leg ran, and in tests/test_gpu_parity.py for all of them.
-        nq, nb = args.multi_queries, args.planner_expansions
+        # ---- the same query through an SBPL-shaped loop: plain GetSuccs / GetGoalHeuristic, no hints -----------------
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                from smpl_amd.plugin_tools import build_driver, write_query
+                import copy
+                exe = build_driver("sbpl_loop_driver", td)
+                c2 = copy.copy(cfg)
+                c2.start, c2.goal = list(q_start), list(q_goal)
+                write_query(c2, td, [p.eps0, p.eps_final, p.eps_delta, nb, nb])
+                pr = subprocess.run([exe, td, "log"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                lines = {l.split(" ", 1)[0]: l.split(" ", 1)[1] if " " in l else "" for l in pr.stdout.decode().splitlines()}
+                if pr.returncode == 0 and "result" in lines:
+                    solved, cost, nexp, plen, secs, eps = lines["result"].split()
+                    st = dict(kv.split("=") for kv in lines.get("stats", "").split()) if "stats" in lines else {}
+                    out["planner_plain"] = {
+                        "caller": "SBPL-shaped ARA* (tests/cpp/sbpl_loop_driver.cpp) over include/smpl_amd/plugin.hpp; only "
+                                  "GetSuccs / GetGoalHeuristic, no smplx_hint_frontier",
+                        "states_expanded_per_s": round(int(nexp) / float(secs), 1), "expansions": int(nexp),
+                        "path_cost": int(cost), "seconds": round(float(secs), 4), **{k: int(v) for k, v in st.items()},
+                        "log_equals_smplx_plan": bool(np.array_equal(np.array(lines.get("log", "").split(), dtype=np.int64),
+                                                                     rg["expansion_log"]))}
+                else:
+                    out["planner_plain"] = {"error": pr.stderr.decode()[-300:]}
+        except Exception as e:   # the secondary leg must not take the bench line down
+            out["planner_plain"] = {"error": repr(e)[:300]}
+
+    if not args.no_shard and not args.no_planner:
+        # ---- BASELINE config 4: this rank's 128 queries through smplx_plan_multi -------------------------------------
+        nb = args.shard_expansions
         spaces = []
-        grid_h = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
-        model_h = capi.Model(cfg.robot_text)
-        for qi in range(nq):
-            g = [a + c * scenes.DEG for a, c in zip(cfg.goal, rank_goal_shift(qi))]
-            sp = capi.Space(model_h, grid_h, cfg.mprim, cfg.params, args.batch,
-                            generic_kernels=args.generic_kernels)   # one scene, one robot, Q queries
-            okq, _ = sp.state_valid_batch(np.array([g]))
-            sp.set_goal_joint(g if okq[0] else cfg.goal, cfg.goal_tol)
-            sp.set_start(cfg.start)
+        t_set = time.perf_counter()
+        for a, b in zip(S_mine, G_mine):
+            sp = new_space(1024)
+            sp.set_goal_joint(b, cfg.goal_tol)     # BFS_3D::run for this goal, to completion
+            sp.set_start(a)
             spaces.append(sp)
-        res, wall = capi.Space.plan_multi(spaces, p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb,
-                                          host_threads=args.host_threads)
-        tot = sum(r["expansions"] for r in res)
-        out["planner_multi"] = {
-            "queries": nq, "host_threads": args.host_threads, "expansion_bound_per_query": nb, "wall_seconds": round(wall, 4),
-            "states_expanded_per_s": round(tot / wall, 1), "expansions_total": tot,
-            "solved": int(sum(r["solved"] for r in res)),
-            "gpu_succ_evals_total": int(sum(r["gpu_succ_evals"] for r in res)),
-            "committed_succ_evals": int(sum(r["committed_succ_evals"] for r in res)),
-            "gpu_batches": int(sum(r["gpu_batches"] for r in res)),
-            "first_query_matches_single": bool("planner" in out and res[0]["cost"] == out["planner"]["path_cost"]
-                                               and res[0]["expansions"] == out["planner"]["expansions"])}
+        torch.cuda.synchronize()
+        t_set = time.perf_counter() - t_set
+        if dist is not None:
+            dist.barrier()
+        res, wall = ([], 0.0)
+        if spaces:
+            res, wall = capi.Space.plan_multi(spaces, p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb,
+                                              host_threads=args.host_threads)
+        if dist is not None:
+            dist.barrier()
+        rec = shard.pack_records(first, res)
+        rows = shard.gather_query_records(rec, args.queries_per_gpu, dist, world, dev)    # the one collective of the path
+        tot_exp = sum(r["expansions"] for r in res)
+        tot_commit = sum(r["committed_succ_evals"] for r in res)
+        tot_gpu = sum(r["gpu_succ_evals"] for r in res)
+        sc2 = shard.gather_scalars([tot_exp, wall, tot_commit, tot_gpu, sum(r["gpu_batches"] for r in res), t_set], dist, world, dev)
+        tmax2 = float(sc2[:, 1].max())
+        summ = shard.summarize(rows)
+        out["shard"] = {
+            "workload": f"cfg 4: queries [{first}, {last}) of the seeded list (seed 4) per rank, {args.queries_per_gpu} per GPU, "
+                        f"ARA* eps 5->1, expansion bound {nb} per query, smplx_plan_multi, {args.host_threads} host threads",
+            "queries": summ["queries"], "solved": summ["solved"], "wall_seconds_max": round(tmax2, 4),
+            "states_expanded_per_s": round(float(sc2[:, 0].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
+            "succ_evals_per_s_committed": round(float(sc2[:, 2].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
+            "succ_evals_per_s_gpu_total": round(float(sc2[:, 3].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
+            "expansions_total": summ["expansions_total"], "gpu_batches": int(sc2[:, 4].sum()),
+            "setup_seconds_max": round(float(sc2[:, 5].max()), 3), "cost_checksum": summ["cost_checksum"],
+            "setup_is": "goal + BFS_3D::run + start for every query of the rank, before the timed region"}
+        if single and Oracle is not None and spaces:
+            # the same queries on the oracle, one per host thread ("nproc independent queries in parallel,
+            # one per core"); a bounded sample: every thread takes queries t, t+T, ... until the budget is spent
+            T = host_threads_available(args.cpu_threads)
+            budget = args.cpu_seconds
+            acc = [dict(exp=0, ev=0, plan_s=0.0, setup_s=0.0, n=0, same=True) for _ in range(T)]
+            t_all = time.perf_counter()
+
+            def worker(t):
+                o = Oracle(cfg)
+                k = t
+                while k < len(spaces) and time.perf_counter() - t_all < budget:
+                    ts = time.perf_counter()
+                    o.set_goal_joint(G_mine[k], cfg.goal_tol)
+                    o.set_start(S_mine[k])
+                    acc[t]["setup_s"] += time.perf_counter() - ts
+                    o.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+                    r = o.plan()
+                    acc[t]["exp"] += r["expansions"]; acc[t]["ev"] += r["succ_evals"]; acc[t]["plan_s"] += r["seconds"]
+                    acc[t]["n"] += 1
+                    acc[t]["same"] &= bool(r["cost"] == res[k]["cost"] and r["expansions"] == res[k]["expansions"] and
+                                           np.array_equal(r["expansion_log"], res[k]["expansion_log"]))
+                    k += T
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            busy = max(a["plan_s"] for a in acc) or 1.0
+            nq_cpu = sum(a["n"] for a in acc)
+            out["cpu_shard"] = {
+                "value": round(sum(a["exp"] for a in acc) / busy, 1), "unit": "states expanded/s", "cores": T, "kind": "port",
+                "succ_evals_per_s": round(sum(a["ev"] for a in acc) / busy, 1),
+                "sample": f"{nq_cpu} of the {len(spaces)} shard queries, one per host thread at a time ({T} threads, oracle/ "
+                          f"C++ -O2, same expansion bound), rate = expansions of all threads / longest thread's time inside "
+                          f"plan(); BFS per goal ({sum(a['setup_s'] for a in acc) / max(nq_cpu, 1):.2f} s each on the CPU) excluded on both sides",
+                "all_sampled_queries_identical_to_gpu": bool(all(a["same"] for a in acc)), "host_cores": os.cpu_count()}
         del spaces
 
     if rank == 0:

@@ -118,6 +118,11 @@ int smplx_check_joint_limits(const smplx_space* s, const double* q, int n, uint8
 /* ---- CollisionChecker (smpl/include/smpl/collision_checker.h:48-130) ---- */
 /* isStateValid (collision_space.cpp:532-536) */
 int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* valid, int32_t* lookups);
+/* same with everything resident in HBM: launches on `stream` (a hipStream_t) and returns without synchronising;
+ * d_lookups may be NULL.  One launch = n configurations through FK + sphere trees vs grid + checked link pairs: the
+ * "K2" collision micro-benchmark of sbpl_collision_checking_test/src/benchmark_cc.cpp:234-256 is a loop over this. */
+int smplx_cc_state_valid_batch_device(smplx_space* s, const double* d_q, int n, uint8_t* d_valid, int32_t* d_lookups,
+                                      void* stream);
 /* isStateToStateValid (collision_space.cpp:538-581); lookups/waypoints may be NULL */
 int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, int n, uint8_t* valid,
                               int32_t* lookups, int32_t* waypoints);
@@ -193,6 +198,10 @@ void smplx_space_clear_status(smplx_space* s);
 /* RobotHeuristic::GetGoalHeuristic(state_id) */
 int smplx_get_goal_heuristic(smplx_space* s, int id, int32_t* h);
 int smplx_num_states(const smplx_space* s);
+/* running totals of the space since its goal was last set: out[0] GPU frontier batches, [1] GetSuccs calls served from
+ * the cache, [2] GetSuccs calls that had to wait for a batch, [3] committed successor evaluations, [4] successor
+ * evaluations the GPU performed (incl. speculative), [5] states ("expands"/"stats" of planner_interface.cpp:1438-1446) */
+int smplx_space_counters(const smplx_space* s, int64_t out[6]);
 int smplx_get_state(const smplx_space* s, int id, double* q, int32_t* coord);
 
 /* ---- the caller: ARA* (smpl/src/search/arastar.cpp:107-215,486-582) ---- */
@@ -209,7 +218,9 @@ typedef struct smplx_search_stats {
     double satisfied_eps;
     double seconds;               /* wall time inside replan */
     int64_t gpu_succ_evals;       /* successor evaluations the GPU performed (incl. speculative) */
-    int64_t committed_succ_evals; /* evaluations belonging to committed expansions */
+    int64_t committed_succ_evals; /* evaluations of the committed expansions, counted as the reference performs them:
+                                     once per GetSuccs call, so a state re-expanded in a later ARA* iteration counts
+                                     again although the engine serves the repeat from its committed list */
     int64_t gpu_batches;
     int64_t cache_hits, cache_misses;
     int64_t grid_lookups;

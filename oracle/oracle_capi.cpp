@@ -191,6 +191,19 @@ int orc_state_valid(void* h, const double* q, int* lookups)
     if (lookups) *lookups = (int)(c->grid.lookups - l0);
     return ok ? 1 : 0;
 }
+// n states one after another (the loop of benchmark_cc.cpp:234-256), timed; lookups may be null
+void orc_state_valid_batch_timed(void* h, const double* Q, int n, unsigned char* out, int* lookups, double* seconds)
+{
+    Ctx* c = (Ctx*)h;
+    const int N = c->robot.jointVariableCount();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {
+        int l = 0;
+        out[i] = (unsigned char)orc_state_valid(h, Q + (size_t)i * N, &l);
+        if (lookups) lookups[i] = l;
+    }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 int orc_waypoint_count(void* h, const double* a, const double* b)
 {
     Ctx* c = (Ctx*)h;

@@ -31,7 +31,7 @@ SYMBOLS = [
     "smplx_plan", "smplx_expansion_log_size", "smplx_expansion_log", "smplx_extract_path", "smplx_post_process_path", "smplx_space_specialized", "smplx_model_const_header", "smplx_profile_begin",
     "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read", "smplx_plan_multi",
     "smplx_bfs_metric_goal_distance", "smplx_bfs_metric_start_distance", "smplx_space_status", "smplx_space_clear_status",
-    "smplx_check_joint_limits",
+    "smplx_check_joint_limits", "smplx_cc_state_valid_batch_device", "smplx_space_counters",
 ]
 
 
@@ -239,6 +239,11 @@ class Space:
         out = np.zeros(n, np.uint8); lk = np.zeros(n, np.int32)
         _chk(lib().smplx_cc_state_valid_batch(self.h, _p(q, _dp), n, _p(out, _up), _p(lk, _ip)))
         return out, lk
+
+    def state_valid_batch_device(self, d_q, n, d_valid, d_lookups, stream):
+        """Raw device pointers (ints); launches on `stream`, does not synchronise."""
+        lib().smplx_cc_state_valid_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(lib().smplx_cc_state_valid_batch_device(self.h, d_q, n, d_valid, d_lookups, stream))
 
     def edge_valid_batch(self, a, b):
         a = _f64(a).reshape(-1, self.N); b = _f64(b).reshape(-1, self.N); n = a.shape[0]

@@ -723,8 +723,11 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
         }
         s->done_off[id] = dof;
         s->done_cnt[id] = cnt;
-        s->committed_evals += s->eval_count[id];
     }
+    // every GetSuccs call of the reference runs the whole loop body again (a state re-expanded in a later ARA*
+    // iteration is re-evaluated, manip_lattice.cpp:263-305); here the repeat is served from the committed list, but it
+    // counts as the same number of successor evaluations, so that the figure compares with the CPU planner's
+    s->committed_evals += s->eval_count[id];
     if (s->plain_mode) {
         // the caller is expanding `id` now: mirror its g-updates and (re)rank the successors not yet evaluated
         const uint32_t gp = s->g_est[id];
@@ -1018,6 +1021,15 @@ int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* 
     HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));
     if (lookups) HIP_TRY(hipMemcpyAsync(lookups, s->b_lookups.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+int smplx_cc_state_valid_batch_device(smplx_space* s, const double* d_q, int n, uint8_t* d_valid, int32_t* d_lookups, void* stream)
+{
+    if (!s || !d_q || !d_valid || n <= 0) return set_error(SMPLX_E_ARG, "bad argument");
+    KLAUNCH(s, K_STATE_VALID, k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, (hipStream_t)stream,
+            s->d_space, d_q, n, d_valid, d_lookups);
+    HIP_TRY(hipGetLastError());
     return SMPLX_OK;
 }
 
@@ -1367,6 +1379,14 @@ int smplx_get_goal_heuristic(smplx_space* s, int id, int32_t* h)
 }
 
 int smplx_num_states(const smplx_space* s) { return s ? (int)s->h_of_id.size() : 0; }
+
+int smplx_space_counters(const smplx_space* s, int64_t out[6])
+{
+    if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
+    out[0] = s->gpu_batches; out[1] = s->cache_hits; out[2] = s->cache_misses; out[3] = s->committed_evals;
+    out[4] = s->gpu_evals; out[5] = (int64_t)s->h_of_id.size();
+    return SMPLX_OK;
+}
 
 int smplx_get_state(const smplx_space* s, int id, double* q, int32_t* coord)
 {

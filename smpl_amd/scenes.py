@@ -465,3 +465,71 @@ def shard_range(rank: int, world: int, total: int = 1024, per_rank: int = 128):
     job simply covers a prefix of the list (weak scaling: per-GPU work is fixed)."""
     first = rank * per_rank
     return first, min(first + per_rank, total)
+
+
+# ----------------------------------------------------------------------------
+# K2 micro-benchmark inputs: the reference's own scheme (sbpl_collision_checking_test/src/benchmark_cc.cpp:280-301)
+# ----------------------------------------------------------------------------
+
+class MT19937_64:
+    """std::mt19937_64 (the C++ standard's 64-bit Mersenne twister), block-vectorised in numpy.  Pinned by the
+    standard's own known answer: the 10000th output of a default-seeded (5489) engine is 9981545732273789042."""
+    NN, MM = 312, 156
+
+    def __init__(self, seed: int = 5489):
+        mt = np.zeros(self.NN, np.uint64)
+        x = seed & 0xFFFFFFFFFFFFFFFF
+        mt[0] = x
+        for i in range(1, self.NN):
+            x = (6364136223846793005 * (x ^ (x >> 62)) + i) & 0xFFFFFFFFFFFFFFFF
+            mt[i] = x
+        self.mt = mt
+        self.buf = np.zeros(0, np.uint64)
+
+    def _twist(self):
+        mt = self.mt
+        UM, LM, A = np.uint64(0xFFFFFFFF80000000), np.uint64(0x7FFFFFFF), np.uint64(0xB5026F5AA96619E9)
+        one = np.uint64(1)
+
+        def mix(cur, nxt, far):
+            x = (cur & UM) | (nxt & LM)
+            return far ^ (x >> one) ^ np.where((x & one) != 0, A, np.uint64(0))
+        # element i needs old mt[i+1] and mt[i+156] (new values once i+156 wraps): three dependency-free chunks
+        n, m = self.NN, self.MM
+        mt[0:n - m] = mix(mt[0:n - m], mt[1:n - m + 1], mt[m:n])                   # i in [0, 156): far = old
+        mt[n - m:n - 1] = mix(mt[n - m:n - 1], mt[n - m + 1:n], mt[0:m - 1])      # i in [156, 311): far = new mt[i-156]
+        mt[n - 1:n] = mix(mt[n - 1:n], mt[0:1], mt[m - 1:m])
+        y = mt.copy()
+        y ^= (y >> np.uint64(29)) & np.uint64(0x5555555555555555)
+        y ^= (y << np.uint64(17)) & np.uint64(0x71D67FFFEDA60000)
+        y ^= (y << np.uint64(37)) & np.uint64(0xFFF7EEE000000000)
+        y ^= y >> np.uint64(43)
+        return y
+
+    def raw(self, n: int) -> np.ndarray:
+        out = [self.buf]
+        have = self.buf.shape[0]
+        while have < n:
+            out.append(self._twist())
+            have += self.NN
+        allv = np.concatenate(out)
+        self.buf = allv[n:]
+        return allv[:n]
+
+    def uniform(self, lo, hi, n: int) -> np.ndarray:
+        """n draws of std::uniform_real_distribution<double>(lo, hi) as libstdc++ computes them: generate_canonical
+        takes one 64-bit output, divides by 2^64 (a value that rounds to 1.0 becomes the double below 1.0)."""
+        u = self.raw(n).astype(np.float64) * (1.0 / 18446744073709551616.0)
+        u = np.where(u >= 1.0, np.nextafter(1.0, 0.0), u)
+        return u * (hi - lo) + lo
+
+
+def benchmark_states(limits, n: int = 1 << 20, seed: int = 12345) -> np.ndarray:
+    """n joint states q ~ U[limits], one uniform_real_distribution per variable drawn in variable order for each state
+    (benchmark_cc.cpp:280-301 scheme), std::mt19937_64 seeded with 12345 (SURVEY 8d K2 micro-benchmark)."""
+    g = MT19937_64(seed)
+    nv = len(limits)
+    u = g.raw(n * nv).astype(np.float64) * (1.0 / 18446744073709551616.0)
+    u = np.where(u >= 1.0, np.nextafter(1.0, 0.0), u).reshape(n, nv)
+    lo = np.array([l for (l, h) in limits]); hi = np.array([h for (l, h) in limits])
+    return u * (hi - lo) + lo

@@ -255,6 +255,10 @@ int main(int argc, char** argv)
     if (lattice.engineStatus(&msg) != SMPLX_OK) { fprintf(stderr, "engine error: %s\n", msg.c_str()); return 6; }
     printf("result %d %d %d %zu %.6f %.17g\n", ok ? 1 : 0, ok ? cost : 0, planner.expansions, ok ? path.size() : (size_t)0, secs,
            planner.satisfied_eps);
+    int64_t ctr[6] = {0, 0, 0, 0, 0, 0};
+    smplx_space_counters(ctx.space(), ctr);
+    printf("stats gpu_batches=%lld cache_hits=%lld cache_misses=%lld committed_succ_evals=%lld gpu_succ_evals_total=%lld states=%lld\n",
+           (long long)ctr[0], (long long)ctr[1], (long long)ctr[2], (long long)ctr[3], (long long)ctr[4], (long long)ctr[5]);
     // metric distances through the heuristic mirror (RobotHeuristic virtuals), goal pose first
     double gp[3];
     smplx_goal_pose(ctx.space(), gp);

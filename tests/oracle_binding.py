@@ -139,6 +139,13 @@ class Oracle:
         ok = self.lib.orc_state_valid(self.h, _p(q, _dp), C.byref(l))
         return bool(ok), l.value
 
+    def state_valid_batch_timed(self, Q):
+        Q = np.ascontiguousarray(Q, np.float64).reshape(-1, self.N)
+        n = Q.shape[0]; out = np.zeros(n, np.uint8); lk = np.zeros(n, np.int32); sec = C.c_double()
+        self.lib.orc_state_valid_batch_timed.argtypes = [C.c_void_p, _dp, C.c_int, _up, _ip, _dp]
+        self.lib.orc_state_valid_batch_timed(self.h, _p(Q, _dp), n, _p(out, _up), _p(lk, _ip), C.byref(sec))
+        return out, lk, sec.value
+
     def waypoint_count(self, a, b):
         a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64)
         return self.lib.orc_waypoint_count(self.h, _p(a, _dp), _p(b, _dp))

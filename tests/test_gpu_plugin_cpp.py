@@ -11,29 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_driver(name, out_dir):
-    from smpl_amd import build
-    lib = build.build()
-    exe = os.path.join(str(out_dir), name)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
-                           lib, f"-Wl,-rpath,{os.path.dirname(lib)}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
-                           "-lamdhip64"])
-    return exe
-
-
-def write_query(cfg, out_dir, tail):
-    """robot.txt, mprim.txt, grid.bin and query.txt (scene + params + start + goal + tolerances + `tail`)."""
-    out_dir = str(out_dir)
-    open(os.path.join(out_dir, "robot.txt"), "w").write(cfg.robot_text)
-    open(os.path.join(out_dir, "mprim.txt"), "w").write(cfg.mprim)
-    np.ascontiguousarray(cfg.grid.d2, np.int32).tofile(os.path.join(out_dir, "grid.bin"))
-    p, g = cfg.params, cfg.grid
-    fields = [*g.origin, *g.dims, g.res, g.max_dist, len(cfg.start), *p.resolutions, p.bfs_radius, p.cost_per_cell,
-              int(p.use_short), p.short_thresh, int(p.use_xyzrpy_snap), p.xyzrpy_thresh, int(p.xy_rotate_by_var3),
-              int(p.use_long_and_short), *cfg.start, *cfg.goal, *cfg.goal_tol, *tail]
-    open(os.path.join(out_dir, "query.txt"), "w").write(
-        " ".join(repr(float(x)) if isinstance(x, float) else str(x) for x in fields))
+from smpl_amd.plugin_tools import build_driver, write_query  # noqa: E402
 
 
 def test_cpp_plugin_driver_matches_oracle(small_cfg, tmp_path):
