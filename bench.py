@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--planner-expansions", type=int, default=40000)
     ap.add_argument("--queries-per-gpu", type=int, default=128, help="config-4 shard size per rank")
     ap.add_argument("--shard-expansions", type=int, default=20000, help="expansion bound per query in the shard leg")
-    ap.add_argument("--host-threads", type=int, default=4, help="host threads driving query slices in the shard leg")
+    ap.add_argument("--host-threads", type=int, default=12,
+                    help="worker threads of smplx_plan_multi in the shard leg (searches and commits; one more thread submits to the GPU)")
     ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="timed steps whose kernels are bracketed by HIP events (default: steps/8, at least 1); every "
@@ -446,7 +447,7 @@ def main():
         summ = shard.summarize(rows)
         out["shard"] = {
             "workload": f"cfg 4: queries [{first}, {last}) of the seeded list (seed 4) per rank, {args.queries_per_gpu} per GPU, "
-                        f"ARA* eps 5->1, expansion bound {nb} per query, smplx_plan_multi, {args.host_threads} host threads",
+                        f"ARA* eps 5->1, expansion bound {nb} per query, smplx_plan_multi, {args.host_threads} worker threads + 1 GPU submitter",
             "queries": summ["queries"], "solved": summ["solved"], "wall_seconds_max": round(tmax2, 4),
             "states_expanded_per_s": round(float(sc2[:, 0].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
             "succ_evals_per_s_committed": round(float(sc2[:, 2].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
@@ -463,10 +464,10 @@ def main():
             t_all = time.perf_counter()
 
             def worker(t):
-                o = Oracle(cfg)
                 k = t
                 while k < len(spaces) and time.perf_counter() - t_all < budget:
                     ts = time.perf_counter()
+                    o = Oracle(cfg)               # a fresh context per query: ids restart at the goal (0) and the start (1)
                     o.set_goal_joint(G_mine[k], cfg.goal_tol)
                     o.set_start(S_mine[k])
                     acc[t]["setup_s"] += time.perf_counter() - ts

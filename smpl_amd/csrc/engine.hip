@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -411,10 +412,28 @@ ExpandWork carve_work(void* base, int B, int M)
     return k;
 }
 
+// pinned host buffers of a zero-copy small batch: the kernel reads the parents from, and also writes the results to, host
+// memory (a few KB of PCIe traffic instead of DMA copies with their fixed latency)
+struct ZeroCopy {
+    const double* q = nullptr;
+    unsigned char* flags = nullptr;
+    int32_t* coord = nullptr;
+    double* sq = nullptr;
+    int32_t* h = nullptr;
+};
+
+bool small_kernel_fits(const smplx_space* s, int B)
+{
+    const int small_block = smplx_small_block(s->M);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    return !s->fused_mode && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list &&
+           s->pipeline_left == 0;
+}
+
 int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
                   hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr,
-                  const smplx_space* zero_copy = nullptr)
+                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false)
 {
     ExpandWork k = carve_work(d_work, B, s->M);
     if (s->tiny_work_list) k.capacity = 8 * 16;   // test hook: almost every edge overflows into the deferred pass
@@ -425,16 +444,16 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int64_t* norefs = nullptr;
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
-    if (!s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list &&
-        s->pipeline_left == 0) {
+    if (!force_pipeline && !s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
+        !s->tiny_work_list && s->pipeline_left == 0) {
         ++s->small_launches;
         // a handful of states: ONE launch, all FK chains side by side (kernels.hip k_small_batch)
         // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
-        const double* qsrc = zero_copy ? zero_copy->p_q.p : d_q;
+        const double* qsrc = zero_copy ? zero_copy->q : d_q;
         KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
-                           zero_copy ? zero_copy->pv.flags : (unsigned char*)nullptr, zero_copy ? zero_copy->pv.coord : (int32_t*)nullptr,
-                           zero_copy ? zero_copy->pv.sq : (double*)nullptr, zero_copy ? zero_copy->pv.h : (int32_t*)nullptr);
+                           zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
+                           zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (ev) (void)hipEventRecord(ev[0], stream);
@@ -634,8 +653,10 @@ int issue_batch(smplx_space* s, int id)
     s->inflight_small = s->inflight_zero_copy;
     s->t_issue = std::chrono::steady_clock::now();
     if (s->inflight_zero_copy) {
+        ZeroCopy zc;
+        zc.q = s->p_q.p; zc.flags = s->pv.flags; zc.coord = s->pv.coord; zc.sq = s->pv.sq; zc.h = s->pv.h;
         if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, s))) return e;
+                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc))) return e;
         HIP_TRY(hipEventRecord(s->batch_done, s->stream));
         ++s->gpu_batches;
         return SMPLX_OK;
@@ -650,9 +671,10 @@ int issue_batch(smplx_space* s, int id)
 }
 
 // the batch in flight has completed: turn its dense outputs into cached successor records
-int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0)
+int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0, const OutView* view = nullptr)
 {
-    if (!src) src = s;   // a cross-query batch lands in the leading space's buffers, at row `first`
+    if (!src) src = s;   // a cross-query batch lands in the leading space's buffers (or in `view`), at row `first`
+    const OutView& pv = view ? *view : src->pv;
     const int N = s->N, M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
@@ -669,16 +691,16 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         int cnt = 0, evals = 0;
         for (int p = 0; p < M; ++p) {
             const size_t k = (first + (size_t)i) * M + p;
-            const unsigned char f = src->pv.flags[k];
+            const unsigned char f = pv.flags[k];
             if (!(f & SMPLX_F_INACTIVE)) ++evals;
             if (!(f & SMPLX_F_VALID)) continue;
             smplx_space::Rec r;
             r.cost = s->actions.dev.cost[p];
-            r.h = src->pv.h[k];
+            r.h = pv.h[k];
             r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
             s->recs.push_back(r);
-            s->rec_coord.insert(s->rec_coord.end(), &src->pv.coord[k * N], &src->pv.coord[k * N] + N);
-            s->rec_q.insert(s->rec_q.end(), &src->pv.sq[k * N], &src->pv.sq[k * N] + N);
+            s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
+            s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
             ++cnt;
         }
         s->cache_cnt[sid] = cnt;
@@ -1544,12 +1566,17 @@ struct Search {
     bool ready(int sid) const { return sid == 0 || sp->done_off[sid] >= 0 || sp->cache_off[sid] >= 0; }
 
     enum { R_DONE = 0, R_YIELD = 100 };
+    int pause_after = 0;   // > 0: hand control back after that many expansions without a miss (miss_id = -1): keeps the
+                           // rounds of the pipelined multi-query driver even; the search resumes at exactly this point
     int improve_path(int& elapsed)   // arastar.cpp:486-527; returns R_YIELD when a frontier batch was issued
     {
+        int since_entry = 0;
         while (!heap_empty()) {
             const int m = heap[1];
             if (st[m].f >= st[goal_id].f || m == goal_id) return 0;
             if (timed_out(elapsed)) return 4;
+            if (pause_after > 0 && since_entry >= pause_after) { miss_id = -1; return R_YIELD; }
+            ++since_entry;
             if (!ready(m)) {
                 // cache miss: the state and the top of OPEN go to the GPU as one frontier batch; the search
                 // resumes from exactly this point when the batch has landed (nothing has been popped yet)
@@ -1675,8 +1702,14 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
         // download of a sweep stays in the hundreds of kilobytes
         const int cap_q = std::max(16, std::min(512, (lead->params.batch_states > 0 ? lead->params.batch_states : 4096) / std::max(1, nq / 4)));
         std::vector<int> reqs;
+        const bool dbg = getenv("SMPLX_DEBUG_TIMING") != nullptr;
+        double t_resume = 0, t_pack = 0, t_gpu = 0, t_collect = 0;
+        long sweeps = 0, swept_states = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         while (remaining > 0) {
             reqs.clear();
+            const auto tr0 = now();
             for (int q = q0; q < q1; ++q) {
                 if (done[q]) continue;
                 const int r = S[q].resume();
@@ -1686,9 +1719,12 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
                 --remaining;
                 t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
+            const auto tr1 = now();
+            t_resume += secs(tr0, tr1);
             if (reqs.empty()) break;
             size_t total = 0;
             for (int q : reqs) { select_batch(spaces[q], S[q].miss_id, cap_q); total += spaces[q]->inflight.size(); }
+            ++sweeps; swept_states += (long)total;
             const int B = (int)total;
             const size_t BM = total * M;
             int e;
@@ -1710,12 +1746,16 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
                     ++row;
                 }
             }
+            const auto tp1 = now();
+            t_pack += secs(tr1, tp1);
             HIP_TRY(hipMemcpyAsync(lead->b_q.p, lead->p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, lead->stream));
             HIP_TRY(hipMemcpyAsync(lead->b_stateq.p, lead->p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, lead->stream));
             if ((e = launch_expand(lead, lead->b_q.p, B, lead->dv.flags, lead->dv.coord, lead->dv.sq, lead->dv.h, lead->b_cost.p,
                                    lead->b_lookups.p, lead->b_work.p, nullptr, lead->stream, lead->b_stab.p, lead->b_stateq.p))) return e;
             HIP_TRY(hipMemcpyAsync(lead->p_out.p, lead->b_out.p, out_bytes, hipMemcpyDeviceToHost, lead->stream));
             HIP_TRY(hipStreamSynchronize(lead->stream));
+            const auto tg1 = now();
+            t_gpu += secs(tp1, tg1);
             ++lead->gpu_batches;
             row = 0;
             for (int q : reqs) {
@@ -1723,7 +1763,240 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
                 if ((e = collect_batch(spaces[q], lead, row))) return e;
                 row += nb;
             }
+            t_collect += secs(tg1, now());
         }
+        if (dbg) fprintf(stderr, "[smplx timing] slice [%d,%d): %ld sweeps, %.1f states/sweep; search+commit %.3fs pack %.3fs gpu(issue..sync) %.3fs collect %.3fs\n",
+                         q0, q1, sweeps, sweeps ? (double)swept_states / sweeps : 0.0, t_resume, t_pack, t_gpu, t_collect);
+    return SMPLX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Asynchronous multi-query driver (host_threads > 1).  Measured on MI355X with the 128 queries of the config-4 shard:
+// the sequential host work per expansion (heap, commit, hashing, record ingestion: about 4.7 us) outweighs the GPU time
+// of a sweep 15:1 on one thread; several threads that each launch their own sweeps queue up behind each other in the
+// runtime (8 threads: 800 us per sweep); and a round barrier between "all searches" and "one batch" makes every round
+// as long as its slowest query.  So there are no rounds:
+//   * T worker threads own the queries (static ownership: a query's heap and tables stay in one core's caches).  A worker
+//     runs a query until it misses, leaves the request in the query's slot and turns to its next query; it makes no
+//     HIP call at all.
+//   * ONE submitter thread owns the GPU.  Whenever a buffer set is free it takes every request pending at that moment
+//     into one cross-query frontier batch (per-state query index -> that query's goal and BFS grid), launches it and
+//     moves on; up to kInFlight batches are in flight on their own streams, so the launch and copy overhead of one
+//     hides behind the kernels of the other.  A landed batch is announced per query; the owner ingests it when it
+//     comes round.
+// Every query sees only its own successor records, in its own sequential order: results are those of a solo run.
+// ---------------------------------------------------------------------------------------------------------------
+struct BatchBuffers {
+    DevBuf<double> b_q;
+    DevBuf<unsigned short> b_stateq;
+    DevBuf<unsigned char> b_work, b_out;
+    DevBuf<int32_t> b_cost, b_lookups;
+    PinBuf<double> p_q;
+    PinBuf<unsigned short> p_stateq;
+    PinBuf<unsigned char> p_out;
+    OutView dv, pv;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    std::atomic<int> uncollected{0};   // queries of the batch that landed in this set and have not been ingested yet
+    std::vector<int> queries;          // the queries of the batch in flight
+    bool in_flight = false;
+    size_t total = 0;
+};
+
+enum { QS_RUNNABLE = 0, QS_REQUESTED = 1, QS_LANDED = 2, QS_IN_FLIGHT = 3 };
+
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
+int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* done, double* t_done,
+                  std::chrono::steady_clock::time_point t0)
+{
+    enum { kSets = 8, kInFlight = 4, kSmallZeroCopyMax = 16 };
+    smplx_space* lead = spaces[0];
+    const int N = lead->N, M = lead->M;
+    std::vector<std::atomic<int>> qstate(nq);
+    std::vector<long> row_of(nq, -1);
+    std::vector<int> set_of(nq, -1);
+    std::atomic<int> remaining{nq}, error{0};
+    std::string error_msg;
+    for (int q = 0; q < nq; ++q) { qstate[q].store(QS_RUNNABLE); S[q].defer_issue = true; S[q].pause_after = 16; }
+    {
+        std::vector<const SmplxSpaceDev*> tab(nq);
+        for (int q = 0; q < nq; ++q) tab[q] = spaces[q]->d_space;
+        if (int e = lead->b_stab.reserve(nq)) return e;
+        HIP_TRY(hipMemcpy(lead->b_stab.p, tab.data(), sizeof(void*) * nq, hipMemcpyHostToDevice));
+    }
+    const int cap_q = std::max(16, std::min(512, (lead->params.batch_states > 0 ? lead->params.batch_states : 4096) / std::max(1, nq / 8)));
+    const bool dbg = getenv("SMPLX_DEBUG_TIMING") != nullptr;
+    const int device = lead->device;
+    int issue_percent = 45;
+    if (const char* e = getenv("SMPLX_ISSUE_PERCENT")) issue_percent = std::max(1, std::min(100, atoi(e)));
+    std::vector<BatchBuffers> sets(kSets);
+
+    auto fail = [&](int code, const std::string& msg) {
+        int expect = 0;
+        if (error.compare_exchange_strong(expect, code)) error_msg = msg;
+    };
+
+    // worker w owns the queries q with q % nworkers == w
+    auto worker = [&](int w) {
+        double t_work = 0;
+        const auto w_begin = std::chrono::steady_clock::now();
+        while (remaining.load(std::memory_order_acquire) > 0 && error.load(std::memory_order_relaxed) == 0) {
+            bool progressed = false;
+            for (int q = w; q < nq; q += nworkers) {
+                if (done[q]) continue;
+                int st = qstate[q].load(std::memory_order_acquire);
+                if (st == QS_REQUESTED || st == QS_IN_FLIGHT) continue;
+                const auto a0 = std::chrono::steady_clock::now();
+                if (st == QS_LANDED) {
+                    BatchBuffers& Bf = sets[set_of[q]];
+                    if (int e = collect_batch(spaces[q], lead, (size_t)row_of[q], &Bf.pv)) { fail(e, g_error); return; }
+                    Bf.uncollected.fetch_sub(1, std::memory_order_acq_rel);
+                    qstate[q].store(QS_RUNNABLE, std::memory_order_relaxed);
+                }
+                const int r = S[q].resume();
+                progressed = true;
+                if (S[q].error) { fail(S[q].error, g_error); return; }
+                if (r == Search::R_YIELD) {
+                    if (S[q].miss_id >= 0) {
+                        select_batch(spaces[q], S[q].miss_id, cap_q);
+                        qstate[q].store(QS_REQUESTED, std::memory_order_release);
+                    }
+                } else {
+                    done[q] = 1;
+                    t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    remaining.fetch_sub(1, std::memory_order_acq_rel);
+                }
+                t_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+            }
+            if (!progressed) cpu_relax();
+        }
+        if (dbg) {
+            const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - w_begin).count();
+            fprintf(stderr, "[smplx timing] worker %d: search+commit+ingest %.3fs of %.3fs\n", w, t_work, tot);
+        }
+    };
+
+    auto submitter = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        for (BatchBuffers& Bf : sets) {
+            HIP_TRY(hipStreamCreate(&Bf.stream));
+            HIP_TRY(hipEventCreateWithFlags(&Bf.done, hipEventDisableTiming));
+        }
+        long sweeps = 0, states = 0;
+        double t_issue = 0;
+        int in_flight = 0, next_set = 0, oldest = 0;
+        while (remaining.load(std::memory_order_acquire) > 0 && error.load(std::memory_order_relaxed) == 0) {
+            bool did = false;
+            // retire landed batches in issue order
+            while (in_flight > 0) {
+                BatchBuffers& Bf = sets[oldest];
+                const hipError_t st = hipEventQuery(Bf.done);
+                if (st == hipErrorNotReady) break;
+                if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+                Bf.uncollected.store((int)Bf.queries.size(), std::memory_order_relaxed);
+                for (int q : Bf.queries) qstate[q].store(QS_LANDED, std::memory_order_release);
+                Bf.in_flight = false;
+                oldest = (oldest + 1) % kSets;
+                --in_flight;
+                did = true;
+            }
+            // issue: every request pending right now, if a buffer set is free
+            BatchBuffers& Nf = sets[next_set];
+            if (in_flight < kInFlight && !Nf.in_flight && Nf.uncollected.load(std::memory_order_acquire) == 0) {
+                const auto i0 = std::chrono::steady_clock::now();
+                // A batch costs the GPU about 80 us whatever its size (rocprofv3: 36 us of kernels, the rest copies and
+                // dependencies), and batches of different streams were not seen to overlap.  Taking every request the
+                // moment it appears gives many small batches (27 queries each with 128 live) and a query then waits for
+                // ~5 batch times per miss.  So a batch is issued when about half of the live queries are waiting:
+                // one half of them is on the GPU while the workers run the other half.
+                const int live = remaining.load(std::memory_order_acquire);
+                int pending = 0;
+                for (int q = 0; q < nq; ++q) pending += qstate[q].load(std::memory_order_acquire) == QS_REQUESTED ? 1 : 0;
+                const int threshold = std::max(1, (live * issue_percent + 99) / 100);
+                Nf.queries.clear();
+                size_t total = 0;
+                if (pending >= threshold) {
+                    for (int q = 0; q < nq; ++q) {
+                        if (qstate[q].load(std::memory_order_acquire) != QS_REQUESTED) continue;
+                        row_of[q] = (long)total;
+                        set_of[q] = next_set;
+                        total += spaces[q]->inflight.size();
+                        Nf.queries.push_back(q);
+                    }
+                }
+                if (total > 0) {
+                    const int B = (int)total;
+                    const size_t BM = total * M;
+                    int e;
+                    if ((e = Nf.b_q.reserve(total * N))) return e;
+                    if ((e = Nf.b_work.reserve(expand_work_bytes(B, M)))) return e;
+                    if ((e = Nf.b_cost.reserve(BM))) return e;
+                    if ((e = Nf.b_lookups.reserve(BM))) return e;
+                    if ((e = Nf.b_stateq.reserve(total))) return e;
+                    if ((e = Nf.p_stateq.reserve(total))) return e;
+                    if ((e = Nf.p_q.reserve(total * N))) return e;
+                    const size_t out_bytes = carve_out(nullptr, BM, N).bytes;
+                    if ((e = Nf.b_out.reserve(out_bytes))) return e;
+                    if ((e = Nf.p_out.reserve(out_bytes))) return e;
+                    Nf.dv = carve_out(Nf.b_out.p, BM, N);
+                    Nf.pv = carve_out(Nf.p_out.p, BM, N);
+                    size_t row = 0;
+                    for (int q : Nf.queries) {
+                        const smplx_space* sq = spaces[q];
+                        for (int32_t id : sq->inflight) {
+                            std::memcpy(&Nf.p_q.p[row * N], &sq->qs[(size_t)id * N], sizeof(double) * N);
+                            Nf.p_stateq.p[row] = (unsigned short)q;
+                            ++row;
+                        }
+                        qstate[q].store(QS_IN_FLIGHT, std::memory_order_relaxed);
+                    }
+                    // rocprofv3 on MI355X, 128 queries: the single-launch kernel with its results written straight to host
+                    // memory averages 152 us at ~100 states (it is built for the handful of states a lone query misses
+                    // on: 33 us), the four pipeline kernels together 36 us
+                    if (B <= kSmallZeroCopyMax && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
+                        // one launch, no copies: parents, query indices and results live in pinned host memory
+                        ZeroCopy zc;
+                        zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h;
+                        if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
+                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.p_stateq.p, &zc))) return e;
+                    } else {
+                        HIP_TRY(hipMemcpyAsync(Nf.b_q.p, Nf.p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, Nf.stream));
+                        HIP_TRY(hipMemcpyAsync(Nf.b_stateq.p, Nf.p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, Nf.stream));
+                        if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
+                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, true))) return e;
+                        HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));
+                    }
+                    HIP_TRY(hipEventRecord(Nf.done, Nf.stream));
+                    Nf.in_flight = true;
+                    Nf.total = total;
+                    ++in_flight;
+                    next_set = (next_set + 1) % kSets;
+                    ++lead->gpu_batches;
+                    ++sweeps; states += (long)total;
+                    did = true;
+                    t_issue += std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
+                }
+            }
+            if (!did) cpu_relax();
+        }
+        // drain what is still in flight (only on error paths: with no live query nothing is pending)
+        for (BatchBuffers& Bf : sets) if (Bf.stream) (void)hipStreamSynchronize(Bf.stream);
+        if (dbg) fprintf(stderr, "[smplx timing] submitter: %ld batches, %.1f states/batch; issuing %.3fs (pack + enqueue)\n",
+                         sweeps, sweeps ? (double)states / sweeps : 0.0, t_issue);
+        return SMPLX_OK;
+    };
+
+    std::vector<std::thread> th;
+    for (int w = 0; w < nworkers; ++w) th.emplace_back(worker, w);
+    int rc = submitter();
+    if (rc != SMPLX_OK) fail(rc, g_error);
+    for (auto& x : th) x.join();
+    for (BatchBuffers& Bf : sets) {
+        if (Bf.stream) { (void)hipStreamSynchronize(Bf.stream); (void)hipStreamDestroy(Bf.stream); }
+        if (Bf.done) (void)hipEventDestroy(Bf.done);
+    }
+    if (error.load() != 0) return set_error(error.load(), error_msg);
     return SMPLX_OK;
 }
 
@@ -1782,18 +2055,24 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         std::vector<int> rc(nthreads, SMPLX_OK);
         std::vector<std::string> msg(nthreads);
         auto worker = [&](int t) {
-            const int q0 = (int)((long long)nq * t / nthreads), q1 = (int)((long long)nq * (t + 1) / nthreads);
+            const int nt = (nthreads == 1 || nq < 4) ? 1 : nthreads;
+            const int q0 = (int)((long long)nq * t / nt), q1 = (int)((long long)nq * (t + 1) / nt);
             rc[t] = run_group(spaces, S.data(), q0, q1, done.data(), t_done.data(), t0);
             if (rc[t] != SMPLX_OK) msg[t] = g_error;
         };
-        if (nthreads == 1) {
+        if (nthreads == 1 || nq < 4) {
             worker(0);
-        } else {
+            if (rc[0] != SMPLX_OK) return set_error(rc[0], msg[0]);
+        } else if (getenv("SMPLX_MULTI_SLICES")) {
+            // the round-1 scheme, kept for A/B runs: every host thread launches the sweeps of its own slice
             std::vector<std::thread> th;
             for (int t = 0; t < nthreads; ++t) th.emplace_back(worker, t);
             for (auto& x : th) x.join();
+            for (int t = 0; t < nthreads; ++t) if (rc[t] != SMPLX_OK) return set_error(rc[t], msg[t]);
+        } else {
+            // host_threads worker threads + this thread as the only GPU submitter (run_pipelined)
+            if (int e = run_pipelined(spaces, S.data(), nq, std::min(nthreads, nq), done.data(), t_done.data(), t0)) return e;
         }
-        for (int t = 0; t < nthreads; ++t) if (rc[t] != SMPLX_OK) return set_error(rc[t], msg[t]);
         remaining = 0;
     } else {
         // One host thread drives every query: a query runs until it misses, its frontier batch goes to its own
