@@ -4,7 +4,8 @@
 `value` (BASELINE.json metric, config 2): one STEP = one frontier-batched expansion, B = 4096 open states of a real
 ARA* search on the config-2 scene (7-DOF arm, 256^3 voxel grid @ 0.02 m, tabletop + 64 seeded boxes), every motion
 primitive applied to every state -- the loop body of ManipLattice::GetSuccs (smpl/src/graph/manip_lattice.cpp:263-305)
-for every (state, primitive) -- inputs and outputs resident in HBM.  value = successor evaluations / s, whole job.
+for every (state, primitive), including the state-table lookup of every valid successor and the ballot compaction
+of the valid ones (K5) -- inputs and outputs resident in HBM.  value = successor evaluations / s, whole job.
 
 That figure is a kernel-level rate.  What a caller of the plugin API gets is reported beside it, in the same line:
   planner        one query through smplx_plan (the engine's own ARA*, frontier hints from its OPEN list)
@@ -146,12 +147,22 @@ def main():
     d_lk = torch.zeros(B * M, dtype=torch.int32, device=dev)
     d_work = torch.zeros(space.expand_work_bytes(B), dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(space.counters_bytes(B) // 8, dtype=torch.int64, device=dev)
+    # K5 outputs: ids from the device copy of the state table (it holds the states of the search that produced the
+    # frontier) and the ballot-compacted successor stream
+    rb = space.compact_rec_b_bytes()
+    d_id = torch.zeros(B * M, dtype=torch.int32, device=dev)
+    d_reca = torch.zeros(B * M * 2, dtype=torch.int32, device=dev)
+    d_recb = torch.zeros(B * M * rb, dtype=torch.uint8, device=dev)
+    d_btab = torch.zeros(space.compact_blocks(B) * 4, dtype=torch.int32, device=dev)
+    d_tot = torch.zeros(4, dtype=torch.int32, device=dev)
+    space.table_sync()
     stream = torch.cuda.current_stream()
 
     def step():
-        space.expand_batch_device(d_q.data_ptr(), B, d_flags.data_ptr(), d_coord.data_ptr(), d_sq.data_ptr(),
-                                  d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_work.data_ptr(),
-                                  d_cnt.data_ptr(), stream.cuda_stream)
+        space.expand_batch_k5_device(d_q.data_ptr(), B, d_flags.data_ptr(), d_coord.data_ptr(), d_sq.data_ptr(),
+                                     d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_id.data_ptr(), d_reca.data_ptr(), B * M,
+                                     d_recb.data_ptr(), B * M, d_btab.data_ptr(), d_tot.data_ptr(), d_work.data_ptr(),
+                                     d_cnt.data_ptr(), stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -171,6 +182,11 @@ def main():
     prep_ms, expand_ms, launches = space.profile_end()
     evals, valid, lookups_ref, lookups_done, configs, state_lookups = space.counters_read(d_cnt.data_ptr(), B)
     elapsed = t1 - t0
+    tot_k5 = d_tot.cpu().numpy()
+    known = int((d_id >= 0).sum().item())
+    k5 = {"valid_successors_per_launch": int(tot_k5[0]), "full_records_per_launch": int(tot_k5[1]), "overflow": int(tot_k5[2]),
+          "known_ids_per_launch": known, "table_states": space.num_states() - 1,
+          "compact_bytes_per_launch": int(8 * tot_k5[0] + rb * tot_k5[1]), "dense_bytes_per_launch": int(B * M * (12 * N + 9))}
 
     # whole-job aggregate: units of all ranks / max-over-ranks time (one all-gather of three doubles per rank)
     sc = shard.gather_scalars([float(evals), elapsed, float(valid)], dist, world, dev)
@@ -215,6 +231,7 @@ def main():
         "value_is": "kernel-level rate of the batched step (inputs resident in HBM); rates through the plugin API are in "
                     "planner / planner_plain / shard",
         "valid_fraction": round(valid / max(evals, 1), 4),
+        "k5": k5,
         "kernels": ("per-robot hiprtc build, " + spec_note[:120]) if spec_ok else "generic (" + spec_note[:200] + ")",
         "roofline": roofline,
     }

@@ -173,6 +173,34 @@ int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t*
                               double* d_succ_q, int32_t* d_h, int32_t* d_cost, int32_t* d_lookups,
                               void* d_work, uint64_t* d_counters, void* stream);
 
+/* ---- K5: state table on the device + compacted successor stream --------------------------------------------------
+ * ManipLattice::getHashEntry / createHashEntry (manip_lattice.cpp:1302-1354).  Every space keeps a device copy of its
+ * coordinate -> id table (open addressing over 32-byte slots).  Ids are still ASSIGNED by the host in the caller's
+ * sequential commit order (that order is what makes them the reference's ids); the states committed since the last
+ * batch are inserted on the device at the head of the next one.  The successor kernels look every valid successor's
+ * coordinate up: a hit hands the id back with the batch and the host skips its own lookup when it commits the
+ * successor; a miss (-1) means "not committed when the batch ran" and the host does getOrCreateState as before.
+ * With the compact arguments the same launch also leaves the VALID successors as a stream built with wavefront
+ * ballots (one atomic per region and thread block):
+ *   region A, 8 bytes per valid successor: {id or -1, primitive | goal << 8 | state index in the batch << 9}
+ *   region B, smplx_compact_rec_b_bytes() per successor the host needs in full (unknown coordinate, or goal successor):
+ *             int32 h, int32 coord[nvars], padding to 8 bytes, double q[nvars]
+ *   block_tab[4 b .. 4 b + 3] = {first A, count A, first B, count B} of thread block b (smplx_compact_blocks(B) blocks);
+ *             walking the blocks in order gives the records in (state, primitive) order
+ *   totals[0], totals[1] = records in A, B; totals[2] = 1 if a region was too small (the dense outputs are still complete)
+ * smplx_table_sync pushes pending inserts without a batch.  Env SMPLX_DEVICE_TABLE=0 disables the device table. */
+int smplx_table_sync(smplx_space* s);
+size_t smplx_compact_rec_b_bytes(const smplx_space* s);
+int smplx_compact_blocks(const smplx_space* s, int B);
+/* everything resident in HBM (d_succ_id, and the four compact arguments together, may be NULL); launches on `stream` */
+int smplx_expand_batch_k5_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord, double* d_succ_q,
+                                 int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, int32_t* d_succ_id, int32_t* d_rec_a, int cap_a,
+                                 void* d_rec_b, int cap_b, int32_t* d_block_tab, int32_t* d_totals, void* d_work,
+                                 uint64_t* d_counters, void* stream);
+/* host-pointer form (synchronous): dense flags / coord / succ_q / h / succ_id may be NULL */
+int smplx_expand_batch_k5(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q, int32_t* h,
+                          int32_t* succ_id, int32_t* rec_a, int cap_a, void* rec_b, int cap_b, int32_t* block_tab, int32_t totals[3]);
+
 /* per-kernel timing of the next max_launches expand launches with HIP events recorded on the launch
  * stream (no synchronisation until _end): summed milliseconds of k_state_prep and k_expand.
  * Mirrors the ARAStar/ManipLattice stopwatch hooks (smpl/src/profiling.h:56-117). */

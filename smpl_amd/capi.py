@@ -32,6 +32,7 @@ SYMBOLS = [
     "smplx_profile_end", "smplx_counters_bytes", "smplx_counters_read", "smplx_plan_multi",
     "smplx_bfs_metric_goal_distance", "smplx_bfs_metric_start_distance", "smplx_space_status", "smplx_space_clear_status",
     "smplx_check_joint_limits", "smplx_cc_state_valid_batch_device", "smplx_space_counters",
+    "smplx_table_sync", "smplx_compact_rec_b_bytes", "smplx_compact_blocks", "smplx_expand_batch_k5_device", "smplx_expand_batch_k5",
 ]
 
 
@@ -315,6 +316,39 @@ class Space:
         _chk(lib().smplx_expand_batch(self.h, _p(q, _dp), B, _p(flags, _up), _p(coord, _ip), _p(sq, _dp), _p(h, _ip),
                                       _p(cost, _ip), _p(lk, _ip)))
         return dict(flags=flags, coord=coord, q=sq, h=h, cost=cost, lookups=lk)
+
+    def table_sync(self):
+        _chk(lib().smplx_table_sync(self.h))
+
+    def compact_rec_b_bytes(self):
+        lib().smplx_compact_rec_b_bytes.restype = C.c_size_t
+        return lib().smplx_compact_rec_b_bytes(self.h)
+
+    def compact_blocks(self, B):
+        return lib().smplx_compact_blocks(self.h, B)
+
+    def expand_batch_k5(self, q, cap_a=None, cap_b=None):
+        """Dense outputs + device-table ids + the compacted successor stream (decoded into per-state lists)."""
+        q = _f64(q).reshape(-1, self.N); B = q.shape[0]; M, N = self.M, self.N
+        cap_a = B * M if cap_a is None else cap_a
+        cap_b = B * M if cap_b is None else cap_b
+        flags = np.zeros((B, M), np.uint8); coord = np.zeros((B, M, N), np.int32); sq = np.zeros((B, M, N))
+        h = np.zeros((B, M), np.int32); sid = np.zeros((B, M), np.int32)
+        rb = self.compact_rec_b_bytes(); nb = self.compact_blocks(B)
+        rec_a = np.zeros((cap_a, 2), np.int32); rec_b = np.zeros((cap_b, rb), np.uint8)
+        bt = np.zeros((nb, 4), np.int32); tot = np.zeros(3, np.int32)
+        lib().smplx_expand_batch_k5.argtypes = [C.c_void_p, _dp, C.c_int, _up, _ip, _dp, _ip, _ip, _ip, C.c_int, C.c_void_p, C.c_int,
+                                                _ip, _ip]
+        _chk(lib().smplx_expand_batch_k5(self.h, _p(q, _dp), B, _p(flags, _up), _p(coord, _ip), _p(sq, _dp), _p(h, _ip), _p(sid, _ip),
+                                         _p(rec_a, _ip), cap_a, rec_b.ctypes.data_as(C.c_void_p), cap_b, _p(bt, _ip), _p(tot, _ip)))
+        return dict(flags=flags, coord=coord, q=sq, h=h, succ_id=sid, rec_a=rec_a, rec_b=rec_b, block_tab=bt, totals=tot)
+
+    def expand_batch_k5_device(self, d_q, B, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, d_id, d_rec_a, cap_a, d_rec_b, cap_b,
+                               d_block_tab, d_totals, d_work, d_counters, stream):
+        lib().smplx_expand_batch_k5_device.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_int] +
+                                                       [C.c_void_p] * 5)
+        _chk(lib().smplx_expand_batch_k5_device(self.h, d_q, B, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, d_id, d_rec_a, cap_a,
+                                                d_rec_b, cap_b, d_block_tab, d_totals, d_work, d_counters, stream))
 
     def expand_work_bytes(self, B):
         return lib().smplx_expand_work_bytes(self.h, B)

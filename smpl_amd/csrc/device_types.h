@@ -103,6 +103,33 @@ struct SmplxActionsDev {
     double delta[SMPLX_MAX_PRIMS][SMPLX_MAX_VARS];
 };
 
+// Device copy of the ManipLattice state table (manip_lattice.cpp:1302-1354: coordinate -> state id), open addressing
+// with linear probing.  A slot is `stride` int32: [id + 1 (0 = empty), coord[nvars], padding]; it holds only states the
+// host has committed (ids are assigned in the caller's sequential order), so a hit is always right and a miss only
+// means "not committed when the table was last synchronised".
+struct SmplxTableDev {
+    int32_t* slots;
+    uint32_t mask;        // capacity - 1 (capacity is a power of two)
+    int32_t stride;       // int32 per slot: nvars + 1 rounded up to a multiple of 8 (32-byte sectors)
+    int32_t pad;
+};
+
+// Compacted successor stream of one frontier batch (K5): every VALID successor leaves an 8-byte record {id, meta} in
+// region A -- id = state id if the coordinate is in the device table, else -1; meta = primitive | goal << 8 |
+// state index in the batch << 9 -- and, when the host needs the full data (unknown coordinate, or a goal successor
+// whose own joint values extractPath reports), a record [h, coord[nvars], pad][q[nvars]] in region B.  A block
+// claims one range of each region (wave ballots -> block totals -> one atomic per region), so records appear in
+// (state, primitive) order inside a block; block_tab[4b..4b+3] = {first A, count A, first B, count B} of block b.
+// totals[0] / totals[1] = records in A / B, totals[2] = 1 if a region overflowed (the dense outputs remain valid).
+struct SmplxCompactDev {
+    int32_t* rec_a;              // 2 int32 per record
+    unsigned char* rec_b;        // rec_b_bytes per record
+    int32_t* block_tab;
+    int32_t* totals;             // zeroed by the setup kernel of the same launch sequence
+    int32_t cap_a, cap_b;
+    int32_t rec_b_bytes, pad;
+};
+
 struct SmplxGoalDev {
     int32_t type, pad;
     double angles[SMPLX_MAX_VARS];
@@ -130,4 +157,19 @@ struct SmplxSpaceDev {
     SmplxBfsDev bfs;
     SmplxActionsDev actions;
     SmplxGoalDev goal;
+    SmplxTableDev table;
 };
+
+// hash of a discretised coordinate (host inserts and device lookups must agree; state ids never depend on it)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t smplx_coord_hash(const int32_t* c, int n)
+{
+    uint32_t h = 2166136261u;
+    for (int i = 0; i < n; ++i) h = (h ^ (uint32_t)c[i]) * 16777619u;
+    h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+static inline int smplx_table_stride(int nvars) { return (nvars + 1 + 7) / 8 * 8; }
+static inline int smplx_rec_b_bytes(int nvars) { return ((nvars + 1 + 1) / 2 * 2) * 4 + nvars * 8; }

@@ -153,6 +153,7 @@ struct OutView {
     double* sq = nullptr;
     int32_t* coord = nullptr;
     int32_t* h = nullptr;
+    int32_t* id = nullptr;      // K5: state id of the successor's coordinate in the device table, -1 = not there
     unsigned char* flags = nullptr;
     size_t bytes = 0;
 };
@@ -164,6 +165,7 @@ inline OutView carve_out(unsigned char* base, size_t BM, int N)
     v.sq = (double*)(base + o); o += BM * N * sizeof(double);
     v.coord = (int32_t*)(base + o); o += BM * N * sizeof(int32_t);
     v.h = (int32_t*)(base + o); o += BM * sizeof(int32_t);
+    v.id = (int32_t*)(base + o); o += BM * sizeof(int32_t);
     v.flags = base + o; o += BM;
     v.bytes = (o + 15) / 16 * 16;
     return v;
@@ -228,8 +230,15 @@ struct smplx_space {
     std::vector<int32_t> h_of_id;
     CoordTable table;
     int start_id = -1;
+    // device copy of the state table (K5; SmplxTableDev in hs.table): the states created since the last synchronisation
+    // wait in pending_ins as (query slot, id, coord[N]) triples and go up with the next frontier batch
+    int32_t* d_table = nullptr;
+    size_t table_cap = 0, table_count = 0;
+    std::vector<int32_t> pending_ins;
+    DevBuf<int32_t> b_ins;
+    PinBuf<int32_t> p_ins;
     // speculative successor cache (per state id: evaluated but not yet committed successors)
-    struct Rec { int32_t cost; int32_t h; int32_t goal; };
+    struct Rec { int32_t cost; int32_t h; int32_t goal; int32_t known; };
     std::vector<int64_t> cache_off;     // per id: first record, -1 = not evaluated
     std::vector<int32_t> cache_cnt;
     std::vector<Rec> recs;
@@ -412,6 +421,84 @@ ExpandWork carve_work(void* base, int B, int M)
     return k;
 }
 
+// ---- device copy of the state table (K5) ------------------------------------------------------------------------
+int table_alloc(smplx_space* s, size_t cap)
+{
+    if (s->d_table) (void)hipFree(s->d_table);
+    s->d_table = nullptr;
+    const int stride = smplx_table_stride(s->N);
+    HIP_TRY(hipMalloc((void**)&s->d_table, cap * (size_t)stride * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(s->d_table, 0, cap * (size_t)stride * sizeof(int32_t), s->stream));
+    s->table_cap = cap;
+    s->hs.table.slots = s->d_table;
+    s->hs.table.mask = (uint32_t)(cap - 1);
+    s->hs.table.stride = stride;
+    s->hs.table.pad = 0;
+    return SMPLX_OK;
+}
+
+// load factor above 1/2: a table four times the size, every committed state re-inserted with the next batch
+int table_grow_if_needed(smplx_space* s)
+{
+    if (!s->d_table || s->table_count * 2 <= s->table_cap) return SMPLX_OK;
+    size_t cap = s->table_cap;
+    while (s->table_count * 2 > cap) cap *= 4;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (int e = table_alloc(s, cap)) return e;
+    if (int e = upload_space(s)) return e;
+    const int nstates = (int)s->h_of_id.size();
+    s->pending_ins.clear();
+    s->pending_ins.reserve((size_t)nstates * (s->N + 2));
+    for (int id = 1; id < nstates; ++id) {
+        s->pending_ins.push_back(0);
+        s->pending_ins.push_back(id);
+        s->pending_ins.insert(s->pending_ins.end(), &s->coords[(size_t)id * s->N], &s->coords[(size_t)id * s->N] + s->N);
+    }
+    return SMPLX_OK;
+}
+
+// append the space's pending inserts to a staging array, tagged with its slot in the batch's query table
+void table_take_pending(smplx_space* s, int slot, std::vector<int32_t>& items)
+{
+    const size_t w = (size_t)s->N + 2;
+    const size_t o = items.size();
+    items.insert(items.end(), s->pending_ins.begin(), s->pending_ins.end());
+    for (size_t k = o; k < items.size(); k += w) items[k] = slot;
+    s->pending_ins.clear();
+}
+
+// upload staged inserts and run k_table_insert on `stream` (before the expansion kernels of the same stream)
+int table_upload(smplx_space* lead, const std::vector<int32_t>& items, DevBuf<int32_t>& dbuf, PinBuf<int32_t>& pbuf, hipStream_t stream,
+                 const SmplxSpaceDev* const* stab)
+{
+    if (items.empty()) return SMPLX_OK;
+    const int n = (int)(items.size() / ((size_t)lead->N + 2));
+    if (int e = dbuf.reserve(items.size())) return e;
+    if (int e = pbuf.reserve(items.size())) return e;
+    std::memcpy(pbuf.p, items.data(), items.size() * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(dbuf.p, pbuf.p, items.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_table_insert, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), 0, stream, lead->d_space, stab, dbuf.p, n, lead->N);
+    HIP_TRY(hipGetLastError());
+    return SMPLX_OK;
+}
+
+// the space's own batches: everything pending goes up on its stream
+int table_flush(smplx_space* s, hipStream_t stream)
+{
+    if (!s->d_table) return SMPLX_OK;
+    if (int e = table_grow_if_needed(s)) return e;
+    if (s->pending_ins.empty()) return SMPLX_OK;
+    std::vector<int32_t> items;
+    table_take_pending(s, 0, items);
+    return table_upload(s, items, s->b_ins, s->p_ins, stream, nullptr);
+}
+
+// optional K5 outputs of an expansion launch
+struct K5Out {
+    int32_t* d_id = nullptr;                 // dense [B][M] ids (-1 = unknown)
+    const SmplxCompactDev* cmp = nullptr;    // compact stream (device pointers), or null
+};
+
 // pinned host buffers of a zero-copy small batch: the kernel reads the parents from, and also writes the results to, host
 // memory (a few KB of PCIe traffic instead of DMA copies with their fixed latency)
 struct ZeroCopy {
@@ -420,6 +507,7 @@ struct ZeroCopy {
     int32_t* coord = nullptr;
     double* sq = nullptr;
     int32_t* h = nullptr;
+    int32_t* id = nullptr;
 };
 
 bool small_kernel_fits(const smplx_space* s, int B)
@@ -433,9 +521,14 @@ bool small_kernel_fits(const smplx_space* s, int B)
 int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
                   hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr,
-                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false)
+                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false, const K5Out* k5 = nullptr)
 {
     ExpandWork k = carve_work(d_work, B, s->M);
+    int32_t* d_id = k5 ? k5->d_id : nullptr;
+    SmplxCompactDev cmp;
+    std::memset(&cmp, 0, sizeof(cmp));
+    if (k5 && k5->cmp) cmp = *k5->cmp;
+    if (cmp.rec_a) force_pipeline = true;   // the compact stream is produced by k_pipe_finish
     if (s->tiny_work_list) k.capacity = 8 * 16;   // test hook: almost every edge overflows into the deferred pass
     hipEvent_t* ev = nullptr;
     if (s->prof_used + 3 <= s->prof_events.size()) { ev = &s->prof_events[s->prof_used]; s->prof_used += 3; }
@@ -453,9 +546,11 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
                            zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
-                           zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr);
+                           zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
+                           zero_copy ? zero_copy->id : (int32_t*)nullptr);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
+        if (d_id) HIP_TRY(hipMemsetAsync(d_id, 0xFF, sizeof(int32_t) * (size_t)B * s->M, stream));   // fused mode: no table lookups
         if (ev) (void)hipEventRecord(ev[0], stream);
         KLAUNCH(s, K_STATE_PREP, k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, stab, state_q);
@@ -468,7 +563,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         const size_t lm = s->blob_bytes;
         ++s->pipe_launches;
         KLAUNCH(s, K_PIPE_PREP, k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
-                           k.goal_dist, k.work_count, stab, state_q);
+                           k.goal_dist, k.work_count, stab, state_q, cmp.totals);
         KLAUNCH(s, K_PIPE_SETUP, k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
                            k.work, k.work_count, k.capacity, stab, state_q);
@@ -481,7 +576,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         // edges whose waypoints did not fit the work list (normally none) are walked whole by their finish thread
         KLAUNCH(s, K_PIPE_FINISH, k_pipe_finish, dim3(be), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, d_flags, d_coord, d_sq, d_h,
-                           d_cost, d_lookups, d_counters, k.goal_dist, stab, state_q);
+                           d_cost, d_lookups, d_counters, k.goal_dist, stab, state_q, d_id, cmp);
         if (ev) (void)hipEventRecord(ev[2], stream);
     }
     HIP_TRY(hipGetLastError());
@@ -517,6 +612,12 @@ int new_state(smplx_space* s, const int32_t* coord, const double* q, int32_t h)
     s->eval_count.push_back(0);
     s->table.insert(id, s->coords);
     if (s->plain_mode) s->g_est.push_back(1000000000u);
+    if (s->d_table) {
+        s->pending_ins.push_back(0);
+        s->pending_ins.push_back(id);
+        s->pending_ins.insert(s->pending_ins.end(), coord, coord + s->N);
+        ++s->table_count;
+    }
     return id;
 }
 
@@ -562,6 +663,9 @@ void reset_lattice(smplx_space* s)
     s->plain_mode = false;
     s->table.init(s->N);
     s->start_id = -1;
+    s->pending_ins.clear();
+    s->table_count = 0;
+    if (s->d_table) (void)hipMemsetAsync(s->d_table, 0, s->table_cap * (size_t)s->hs.table.stride * sizeof(int32_t), s->stream);
     // id 0 is reserved for the goal (manip_lattice.cpp:122); it has no coordinate and is never hashed
     s->coords.assign(s->N, 0);
     s->qs.assign(s->N, 0.0);
@@ -652,19 +756,22 @@ int issue_batch(smplx_space* s, int id)
     s->inflight_zero_copy = takes_small_kernel(s, B);
     s->inflight_small = s->inflight_zero_copy;
     s->t_issue = std::chrono::steady_clock::now();
+    if ((e = table_flush(s, s->stream))) return e;   // states committed since the last batch join the device table
+    K5Out k5;
+    k5.d_id = s->dv.id;
     if (s->inflight_zero_copy) {
         ZeroCopy zc;
-        zc.q = s->p_q.p; zc.flags = s->pv.flags; zc.coord = s->pv.coord; zc.sq = s->pv.sq; zc.h = s->pv.h;
+        zc.q = s->p_q.p; zc.flags = s->pv.flags; zc.coord = s->pv.coord; zc.sq = s->pv.sq; zc.h = s->pv.h; zc.id = s->pv.id;
         if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc))) return e;
+                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc, false, &k5))) return e;
         HIP_TRY(hipEventRecord(s->batch_done, s->stream));
         ++s->gpu_batches;
         return SMPLX_OK;
     }
     HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * B * N, hipMemcpyHostToDevice, s->stream));
     if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                           s->b_work.p, s->b_counters.p, s->stream))) return e;
-    HIP_TRY(hipMemcpyAsync(s->p_out.p, s->b_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));   // one copy for all four outputs
+                           s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, nullptr, false, &k5))) return e;
+    HIP_TRY(hipMemcpyAsync(s->p_out.p, s->b_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));   // one copy for all five outputs
     HIP_TRY(hipEventRecord(s->batch_done, s->stream));
     ++s->gpu_batches;
     return SMPLX_OK;
@@ -698,6 +805,7 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
             r.cost = s->actions.dev.cost[p];
             r.h = pv.h[k];
             r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
+            r.known = s->d_table ? pv.id[k] : -1;
             s->recs.push_back(r);
             s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
             s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
@@ -738,7 +846,9 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
         for (int k = 0; k < cnt; ++k) {
             const smplx_space::Rec r = s->recs[off + k];
             const int32_t* c = &s->rec_coord[(size_t)(off + k) * s->N];
-            int sid = s->table.find(c, s->coords);
+            // K5: the device table already named the state when the batch was evaluated (it only holds committed
+            // states, so a hit is final); otherwise getOrCreateState on the host table
+            int sid = r.known >= 0 ? r.known : s->table.find(c, s->coords);
             if (sid < 0) sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
             s->done_succ.push_back(r.goal ? 0 : sid);
             s->done_cost.push_back(r.cost);
@@ -977,6 +1087,13 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     // BfsHeuristic::syncGridAndBfs (bfs_heuristic.cpp:331-353), once, at init
     hipLaunchKernelGGL(k_bfs_init, dim3(2048), dim3(256), 0, s->stream, grid->dev, s->wall_thr, dx, dy, dz, s->d_bfs);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_bfs_init");
+    {
+        // device copy of the state table (K5); SMPLX_DEVICE_TABLE=0 keeps every lookup on the host
+        const char* env = getenv("SMPLX_DEVICE_TABLE");
+        if (!(env && env[0] == '0') && table_alloc(s, (size_t)1 << 18) != SMPLX_OK) {
+            const std::string m = g_error; smplx_space_destroy(s); return set_error(SMPLX_E_HIP, m);
+        }
+    }
     if (upload_space(s) != SMPLX_OK) { const std::string m = g_error; smplx_space_destroy(s); return set_error(SMPLX_E_HIP, m); }
     reset_lattice(s);
     *out = s;
@@ -995,6 +1112,7 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_queue[1]) (void)hipFree(s->d_queue[1]);
     if (s->d_counts) (void)hipFree(s->d_counts);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
+    if (s->d_table) (void)hipFree(s->d_table);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1282,6 +1400,72 @@ int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t*
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first");
     return launch_expand(s, d_q, B, d_flags, d_coord, d_succ_q, d_h, d_cost, d_lookups, d_work,
                          (unsigned long long*)d_counters, (hipStream_t)stream);
+}
+
+int smplx_table_sync(smplx_space* s)
+{
+    if (!s) return set_error(SMPLX_E_ARG, "null argument");
+    if (int e = table_flush(s, s->stream)) return e;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
+}
+
+size_t smplx_compact_rec_b_bytes(const smplx_space* s) { return s ? (size_t)smplx_rec_b_bytes(s->N) : 0; }
+int smplx_compact_blocks(const smplx_space* s, int B) { return s && B > 0 ? blocks_for((long long)B * s->M, SMPLX_BLOCK) : 0; }
+
+int smplx_expand_batch_k5_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord, double* d_succ_q,
+                                 int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, int32_t* d_succ_id, int32_t* d_rec_a, int cap_a,
+                                 void* d_rec_b, int cap_b, int32_t* d_block_tab, int32_t* d_totals, void* d_work,
+                                 uint64_t* d_counters, void* stream)
+{
+    if (!s || !d_q || !d_flags || !d_coord || !d_succ_q || !d_h || !d_cost || !d_lookups || !d_work || B <= 0)
+        return set_error(SMPLX_E_ARG, "bad argument");
+    if (d_rec_a && (!d_rec_b || !d_block_tab || !d_totals || cap_a <= 0 || cap_b <= 0)) return set_error(SMPLX_E_ARG, "incomplete compact-stream arguments");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first");
+    if (s->fused_mode && d_rec_a) return set_error(SMPLX_E_STATE, "the compact stream needs the pipeline kernels (not fused mode)");
+    SmplxCompactDev cmp;
+    std::memset(&cmp, 0, sizeof(cmp));
+    cmp.rec_a = d_rec_a; cmp.rec_b = (unsigned char*)d_rec_b; cmp.block_tab = d_block_tab; cmp.totals = d_totals;
+    cmp.cap_a = cap_a; cmp.cap_b = cap_b; cmp.rec_b_bytes = smplx_rec_b_bytes(s->N);
+    K5Out k5;
+    k5.d_id = d_succ_id;
+    k5.cmp = d_rec_a ? &cmp : nullptr;
+    return launch_expand(s, d_q, B, d_flags, d_coord, d_succ_q, d_h, d_cost, d_lookups, d_work, (unsigned long long*)d_counters,
+                         (hipStream_t)stream, nullptr, nullptr, nullptr, false, &k5);
+}
+
+int smplx_expand_batch_k5(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q, int32_t* h,
+                          int32_t* succ_id, int32_t* rec_a, int cap_a, void* rec_b, int cap_b, int32_t* block_tab, int32_t totals[3])
+{
+    if (!s || !q || B <= 0 || !rec_a || !rec_b || !block_tab || !totals || cap_a <= 0 || cap_b <= 0) return set_error(SMPLX_E_ARG, "bad argument");
+    if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first");
+    if (!sane_values(q, (size_t)B * s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
+    if (int e = reserve_expand(s, B)) return e;
+    const size_t BM = (size_t)B * s->M;
+    const size_t rb = (size_t)smplx_rec_b_bytes(s->N);
+    const int nblocks = blocks_for((long long)BM, SMPLX_BLOCK);
+    int e;
+    if ((e = s->b_way.reserve(BM))) return e;                                       // dense ids
+    if ((e = s->b_ins.reserve(2 * (size_t)cap_a + 4 * (size_t)nblocks + 4))) return e;   // A records | block table | totals
+    if ((e = s->b_out.reserve(rb * (size_t)cap_b))) return e;                       // B records
+    if ((e = table_flush(s, s->stream))) return e;
+    int32_t* d_a = s->b_ins.p;
+    int32_t* d_bt = d_a + 2 * (size_t)cap_a;
+    int32_t* d_tot = d_bt + 4 * (size_t)nblocks;
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * B * s->N, hipMemcpyHostToDevice, s->stream));
+    if ((e = smplx_expand_batch_k5_device(s, s->b_q.p, B, s->b_flags.p, s->b_coord.p, s->b_sq.p, s->b_h.p, s->b_cost.p, s->b_lookups.p,
+                                          s->b_way.p, d_a, cap_a, s->b_out.p, cap_b, d_bt, d_tot, s->b_work.p, nullptr, s->stream))) return e;
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, s->b_flags.p, BM, hipMemcpyDeviceToHost, s->stream));
+    if (coord) HIP_TRY(hipMemcpyAsync(coord, s->b_coord.p, sizeof(int32_t) * BM * s->N, hipMemcpyDeviceToHost, s->stream));
+    if (succ_q) HIP_TRY(hipMemcpyAsync(succ_q, s->b_sq.p, sizeof(double) * BM * s->N, hipMemcpyDeviceToHost, s->stream));
+    if (h) HIP_TRY(hipMemcpyAsync(h, s->b_h.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
+    if (succ_id) HIP_TRY(hipMemcpyAsync(succ_id, s->b_way.p, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(rec_a, d_a, sizeof(int32_t) * 2 * (size_t)cap_a, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(rec_b, s->b_out.p, rb * (size_t)cap_b, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(block_tab, d_bt, sizeof(int32_t) * 4 * (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(totals, d_tot, sizeof(int32_t) * 3, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SMPLX_OK;
 }
 
 size_t smplx_counters_bytes(const smplx_space* s, int B)
@@ -1702,6 +1886,7 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
         // download of a sweep stays in the hundreds of kilobytes
         const int cap_q = std::max(16, std::min(512, (lead->params.batch_states > 0 ? lead->params.batch_states : 4096) / std::max(1, nq / 4)));
         std::vector<int> reqs;
+        std::vector<int32_t> ins_items;
         const bool dbg = getenv("SMPLX_DEBUG_TIMING") != nullptr;
         double t_resume = 0, t_pack = 0, t_gpu = 0, t_collect = 0;
         long sweeps = 0, swept_states = 0;
@@ -1748,10 +1933,22 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
             }
             const auto tp1 = now();
             t_pack += secs(tr1, tp1);
+            {
+                std::vector<int32_t>& items = ins_items;
+                items.clear();
+                for (int q : reqs) {
+                    if ((e = table_grow_if_needed(spaces[q]))) return e;
+                    table_take_pending(spaces[q], q - q0, items);
+                }
+                if ((e = table_upload(lead, items, lead->b_ins, lead->p_ins, lead->stream, lead->b_stab.p))) return e;
+            }
             HIP_TRY(hipMemcpyAsync(lead->b_q.p, lead->p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, lead->stream));
             HIP_TRY(hipMemcpyAsync(lead->b_stateq.p, lead->p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, lead->stream));
+            K5Out k5;
+            k5.d_id = lead->dv.id;
             if ((e = launch_expand(lead, lead->b_q.p, B, lead->dv.flags, lead->dv.coord, lead->dv.sq, lead->dv.h, lead->b_cost.p,
-                                   lead->b_lookups.p, lead->b_work.p, nullptr, lead->stream, lead->b_stab.p, lead->b_stateq.p))) return e;
+                                   lead->b_lookups.p, lead->b_work.p, nullptr, lead->stream, lead->b_stab.p, lead->b_stateq.p,
+                                   nullptr, false, &k5))) return e;
             HIP_TRY(hipMemcpyAsync(lead->p_out.p, lead->b_out.p, out_bytes, hipMemcpyDeviceToHost, lead->stream));
             HIP_TRY(hipStreamSynchronize(lead->stream));
             const auto tg1 = now();
@@ -1794,6 +1991,9 @@ struct BatchBuffers {
     PinBuf<double> p_q;
     PinBuf<unsigned short> p_stateq;
     PinBuf<unsigned char> p_out;
+    DevBuf<int32_t> b_ins;
+    PinBuf<int32_t> p_ins;
+    std::vector<int32_t> ins_items;
     OutView dv, pv;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
@@ -1942,29 +2142,36 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     Nf.dv = carve_out(Nf.b_out.p, BM, N);
                     Nf.pv = carve_out(Nf.p_out.p, BM, N);
                     size_t row = 0;
+                    Nf.ins_items.clear();
                     for (int q : Nf.queries) {
-                        const smplx_space* sq = spaces[q];
+                        smplx_space* sq = spaces[q];
                         for (int32_t id : sq->inflight) {
                             std::memcpy(&Nf.p_q.p[row * N], &sq->qs[(size_t)id * N], sizeof(double) * N);
                             Nf.p_stateq.p[row] = (unsigned short)q;
                             ++row;
                         }
+                        // a requesting query is not being touched by its worker: its committed states join the device table
+                        if ((e = table_grow_if_needed(sq))) return e;
+                        table_take_pending(sq, q, Nf.ins_items);
                         qstate[q].store(QS_IN_FLIGHT, std::memory_order_relaxed);
                     }
+                    if ((e = table_upload(lead, Nf.ins_items, Nf.b_ins, Nf.p_ins, Nf.stream, lead->b_stab.p))) return e;
+                    K5Out k5;
+                    k5.d_id = Nf.dv.id;
                     // rocprofv3 on MI355X, 128 queries: the single-launch kernel with its results written straight to host
                     // memory averages 152 us at ~100 states (it is built for the handful of states a lone query misses
                     // on: 33 us), the four pipeline kernels together 36 us
                     if (B <= kSmallZeroCopyMax && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
                         // one launch, no copies: parents, query indices and results live in pinned host memory
                         ZeroCopy zc;
-                        zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h;
+                        zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h; zc.id = Nf.pv.id;
                         if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
-                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.p_stateq.p, &zc))) return e;
+                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.p_stateq.p, &zc, false, &k5))) return e;
                     } else {
                         HIP_TRY(hipMemcpyAsync(Nf.b_q.p, Nf.p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, Nf.stream));
                         HIP_TRY(hipMemcpyAsync(Nf.b_stateq.p, Nf.p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, Nf.stream));
                         if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
-                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, true))) return e;
+                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, true, &k5))) return e;
                         HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));
                     }
                     HIP_TRY(hipEventRecord(Nf.done, Nf.stream));

@@ -35,7 +35,7 @@ __global__ void k_expand(const SmplxSpaceDev* S, const double* Q, const int64_t*
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_prep(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist,
                             int* work_count,
-                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q, int* cmp_totals);
 __global__ void k_pipe_setup(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
                              unsigned char* out_flags, double* out_q, int* edge_w, int* edge_lookups,
                              unsigned char* edge_bad, int* state_lookups, unsigned char* state_bad, unsigned long long* work,
@@ -49,17 +49,18 @@ __global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int
                               const unsigned char* state_bad, unsigned char* out_flags, int* out_coord, double* out_q,
                               int* out_h, int* out_cost, int* out_lookups, unsigned long long* counters,
                               const double* goal_dist,
-                         const SmplxSpaceDev* const* stab, const unsigned short* state_q);
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q, int* out_id, SmplxCompactDev cmp);
 __global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist_out,
                               unsigned char* state_bad_out, int* state_lookups_out, unsigned char* out_flags, int* out_coord,
                               double* out_q, int* out_h, int* out_cost, int* out_lookups, int* deferred_count,
                               const SmplxSpaceDev* const* stab, const unsigned short* state_q, unsigned char* host_flags,
-                              int* host_coord, double* host_q, int* host_h);
+                              int* host_coord, double* host_q, int* host_h, int* out_id, int* host_id);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);
 __global__ void k_heuristic(const SmplxSpaceDev* S, const double* Q, int n, int* out_h, double* out_xyz);
 __global__ void k_sphere_positions(const SmplxSpaceDev* S, const double* Q, int n, double* out);
+__global__ void k_table_insert(const SmplxSpaceDev* S, const SmplxSpaceDev* const* stab, const int* items, int n, int nvars);
 __global__ void k_bfs_metric(SmplxGridDev grid, SmplxBfsDev bfs, const double* xyz, int n, double* out);
 __global__ void k_bfs_init(SmplxGridDev g, int wall_thr, int dim_x, int dim_y, int dim_z, int* dist);
 __global__ void k_bfs_reset(int* dist, size_t total);

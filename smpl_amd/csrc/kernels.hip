@@ -849,6 +849,23 @@ __device__ __forceinline__ int var_to_coord(const ModelLds* __restrict__ M, int 
     return (int)(((x - MV_MIN(M, v)) / delta) + 0.5);
 }
 
+// ManipLattice::getHashEntry (manip_lattice.cpp:1302-1316) against the device copy of the state table: state id of a
+// discretised coordinate, -1 if the host has not committed it (yet)
+__device__ __forceinline__ int table_lookup(const SmplxTableDev& T, const int* __restrict__ c, int nv)
+{
+    if (!T.slots) return -1;
+    unsigned int i = smplx_coord_hash(c, nv) & T.mask;
+    while (true) {
+        const int* sl = T.slots + (size_t)i * T.stride;
+        const int tag = sl[0];
+        if (tag == 0) return -1;
+        bool same = true;
+        for (int v = 0; v < nv; ++v) same = same && sl[1 + v] == c[v];
+        if (same) return tag - 1;
+        i = (i + 1) & T.mask;
+    }
+}
+
 // Cooperative copy of the packed model (a few KB) into LDS in 16-byte pieces, all loads of a thread issued before
 // its first store; every later read of the model is a uniform-address LDS broadcast instead of a dependent
 // global load.  Returns the view.
@@ -1177,7 +1194,7 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
 extern "C" __global__ void __launch_bounds__(BLOCK)
 k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
             double* __restrict__ goal_dist, int* __restrict__ work_count,
-        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q, int* __restrict__ cmp_totals)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const ModelLds Mv = setup_model_only(S, smem);
@@ -1185,6 +1202,7 @@ k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, c
     const SmplxGridDev grid = S->grid;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i <= SMPLX_WORK_SHARDS) work_count[i * SMPLX_SHARD_STRIDE] = 0;   // shard counters + deferred count
+    if (cmp_totals && i < 4) cmp_totals[i] = 0;                          // compaction counters of k_pipe_finish
     if (i >= B) return;
     const SmplxBfsDev bfs = (stab ? stab[state_q[i]] : S)->bfs;
     const double* q = Q + (refs ? refs[i] : (int64_t)i) * MV_NVARS(M);
@@ -1374,7 +1392,8 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
               int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
               unsigned long long* __restrict__ counters, const double* __restrict__ goal_dist,
-        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q)
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
+              int* __restrict__ out_id, SmplxCompactDev cmp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const SmplxActionsDev& A = S->actions;
@@ -1383,6 +1402,7 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = tid < (long long)B * nprims;
     int flags = SMPLX_F_INACTIVE, lookups = 0, performed = 0, evaluated = 0;
+    int succ_id = -1, succ_h = 0;   // K5: id of the successor's coordinate in the device state table
     int ncfg = 0, slk = 0;   // configurations k_pipe_configs checked for this edge / lookups of the state's own check
     if (in_range) flags = out_flags[tid];
     // the model and the per-thread scratch are only needed by edges that overflowed the work list (normally none)
@@ -1454,6 +1474,58 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             out_h[tid] = h;
             out_cost[tid] = cost;
             out_lookups[tid] = lookups;
+        } else {
+            h = out_h[tid];
+        }
+        succ_h = h;
+        // K5: getHashEntry on the device copy of the state table (manip_lattice.cpp:1302-1316).  The id is only a
+        // hint to the host (it skips its own lookup); ids are still ASSIGNED on the host, in commit order.
+        if (out_id) {
+            if (flags & SMPLX_F_VALID) succ_id = table_lookup(Sq->table, out_coord + tid * nv, nv);
+            out_id[tid] = succ_id;
+        }
+    }
+    // K5: validity compaction with wavefront ballots.  A valid successor leaves 8 bytes in region A; one whose
+    // coordinate the table does not know (or a goal successor, whose own joint values extractPath reports) also a full
+    // record in region B.  Ballot -> popcount of the lanes below -> wave totals in LDS -> ONE atomic per region and block.
+    if (cmp.rec_a) {
+        __shared__ int c_cnt[BLOCK / 64][2];
+        __shared__ int c_base[2];
+        const bool is_a = in_range && (flags & SMPLX_F_VALID) != 0;
+        const bool is_b = is_a && (succ_id < 0 || (flags & SMPLX_F_GOAL) != 0);
+        const unsigned long long m_a = __ballot(is_a), m_b = __ballot(is_b);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        if (lane == 0) { c_cnt[wv][0] = __popcll(m_a); c_cnt[wv][1] = __popcll(m_b); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int ta = 0, tb = 0;
+#pragma unroll
+            for (int k = 0; k < BLOCK / 64; ++k) { ta += c_cnt[k][0]; tb += c_cnt[k][1]; }
+            int ba = ta > 0 ? atomicAdd(&cmp.totals[0], ta) : 0;
+            const int bb = tb > 0 ? atomicAdd(&cmp.totals[1], tb) : 0;
+            if (ba + ta > cmp.cap_a || bb + tb > cmp.cap_b) { cmp.totals[2] = 1; ba = -1; }   // overflow: dense outputs stay valid
+            c_base[0] = ba; c_base[1] = bb;
+            int* bt = cmp.block_tab + 4 * (size_t)blockIdx.x;
+            bt[0] = ba; bt[1] = ta; bt[2] = bb; bt[3] = tb;
+        }
+        __syncthreads();
+        if (c_base[0] >= 0 && is_a) {
+            int ia = c_base[0] + __popcll(m_a & below), ib = c_base[1] + __popcll(m_b & below);
+            for (int k = 0; k < wv; ++k) { ia += c_cnt[k][0]; ib += c_cnt[k][1]; }
+            const int si = (int)(tid / nprims);
+            const int pi = (int)(tid - (long long)si * nprims);
+            cmp.rec_a[2 * (size_t)ia] = succ_id;
+            cmp.rec_a[2 * (size_t)ia + 1] = pi | ((flags & SMPLX_F_GOAL) ? 0x100 : 0) | (si << 9);
+            if (is_b) {
+                const int nv = MV_NVARS(M);
+                unsigned char* rb = cmp.rec_b + (size_t)ib * cmp.rec_b_bytes;
+                int* ri = (int*)rb;
+                double* rq = (double*)(rb + (size_t)((nv + 2) / 2 * 2) * 4);
+                ri[0] = succ_h;
+                MV_UNROLL
+                for (int v = 0; v < nv; ++v) { ri[1 + v] = out_coord[tid * nv + v]; rq[v] = out_q[tid * nv + v]; }
+            }
         }
     }
     if (counters) {
@@ -1483,7 +1555,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups, int* __restrict__ deferred_count,
               const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
               unsigned char* __restrict__ host_flags, int* __restrict__ host_coord, double* __restrict__ host_q,
-              int* __restrict__ host_h)
+              int* __restrict__ host_h, int* __restrict__ out_id, int* __restrict__ host_id)
 {
     // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
     // as a few KB of PCIe stores than as four DMA copies); Q may itself be pinned host memory -- the parent's
@@ -1642,8 +1714,14 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         out_h[eid] = hh;
         out_cost[eid] = cost;
         out_lookups[eid] = lookups;
+        int sid = -1;
+        if (out_id) {   // K5: device copy of the state table (see k_pipe_finish)
+            if (flags & SMPLX_F_VALID) sid = table_lookup(Sq->table, out_coord + eid * nv, nv);
+            out_id[eid] = sid;
+        }
         if (host_flags) {
             host_flags[eid] = (unsigned char)flags;
+            if (host_id) host_id[eid] = sid;
             if (flags & SMPLX_F_VALID) {
                 host_h[eid] = hh;
                 const int* sc = out_coord + eid * nv;
@@ -1706,6 +1784,31 @@ k_heuristic(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, i
     world_to_cell(S->grid, p, c);
     out_h[i] = bfs_cost_to_goal(S->bfs, c);
     if (out_xyz) { out_xyz[3 * i] = p[0]; out_xyz[3 * i + 1] = p[1]; out_xyz[3 * i + 2] = p[2]; }
+}
+
+// ManipLattice::createHashEntry (manip_lattice.cpp:1318-1354), device side: the host assigns ids in commit order and
+// sends the (query, id, coordinate) triples of the states created since the last batch; a slot is claimed with one CAS
+// on its tag and filled afterwards (lookups run in later launches of the same stream).  items: n x (nvars + 2) int32.
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_table_insert(const SmplxSpaceDev* __restrict__ S, const SmplxSpaceDev* const* __restrict__ stab, const int* __restrict__ items,
+               int n, int nvars)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int* it = items + (size_t)i * (nvars + 2);
+    const SmplxTableDev T = (stab ? stab[it[0]] : S)->table;
+    if (!T.slots) return;
+    const int id = it[1];
+    const int* c = it + 2;
+    unsigned int k = smplx_coord_hash(c, nvars) & T.mask;
+    while (true) {
+        int* sl = T.slots + (size_t)k * T.stride;
+        if (atomicCAS(&sl[0], 0, id + 1) == 0) {
+            for (int v = 0; v < nvars; ++v) sl[1 + v] = c[v];
+            return;
+        }
+        k = (k + 1) & T.mask;
+    }
 }
 
 // BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138) for a batch of workspace points

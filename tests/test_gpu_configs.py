@@ -214,3 +214,82 @@ def test_non_finite_and_absurd_inputs_are_refused(small_cfg):
                 call()
             assert err.value.code == -1
     assert s.state_valid_batch(np.array([cfg.start]))[0][0] == 1      # the space is still usable
+
+
+def test_k5_device_state_table_and_compacted_successor_stream(small_cfg):
+    """K5 (manip_lattice.cpp:1302-1354 on the device): after a search the device copy of the state table names every
+    committed coordinate; the compact stream built with wavefront ballots lists exactly the valid successors in
+    (state, primitive) order, with full records for the unknown ones and the goal successors."""
+    import struct
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    s = capi.Space.from_config(cfg, batch_states=256)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_start(cfg.start)
+    r = s.plan(5.0, 1.0, 1.0, True, True, 1500, 1500)
+    assert r["expansions"] == 1500
+    n = s.num_states()
+    host = {tuple(s.get_state(i)[1]): i for i in range(1, n)}      # the committed table: coordinate -> id
+    assert len(host) == n - 1
+    s.table_sync()
+    g = np.array(cfg.goal)
+    near = np.array([g + np.array([0, 0, 0, 0, 4, 0, 0]) * DEG, g - np.array([0, 0, 0, 0, 0, 4, 0]) * DEG])
+    Q = np.vstack([np.stack([s.get_state(i)[0] for i in range(1, 301)]), near,
+                   scenes.random_states(scenes.ARM7_LIMITS, 60, 17)])
+    B, M, N = Q.shape[0], s.M, s.N
+    dense = s.expand_batch(Q)
+    got = s.expand_batch_k5(Q)
+    for k in ("flags", "coord", "q", "h"):
+        assert np.array_equal(dense[k], got[k]), k
+    valid = (got["flags"] & 1) != 0
+    goal = (got["flags"] & 2) != 0
+    want_id = np.full((B, M), -1, np.int32)
+    for i, p in zip(*np.nonzero(valid)):
+        want_id[i, p] = host.get(tuple(got["coord"][i, p]), -1)
+    assert np.array_equal(got["succ_id"], want_id)
+    assert (want_id[valid] >= 0).sum() > 500 and (want_id[valid] < 0).sum() > 200 and goal.sum() >= 2
+    # the compact stream
+    tot = got["totals"]
+    assert tot[2] == 0 and tot[0] == valid.sum()
+    need_b = valid & ((want_id < 0) | goal)
+    assert tot[1] == need_b.sum()
+    ints = (N + 2) // 2 * 2
+    assert s.compact_rec_b_bytes() == ints * 4 + N * 8
+    seq_a, seq_b = [], []
+    for ba, ca, bb, cb in got["block_tab"]:
+        seq_a += [tuple(x) for x in got["rec_a"][ba:ba + ca]]
+        seq_b += [bytes(x) for x in got["rec_b"][bb:bb + cb]]
+    assert len(seq_a) == tot[0] and len(seq_b) == tot[1]
+    ib = 0
+    for (i, p), (rid, meta) in zip(zip(*np.nonzero(valid)), seq_a):      # np.nonzero is (state, primitive) order
+        assert rid == want_id[i, p]
+        assert meta == (p | (0x100 if goal[i, p] else 0) | (i << 9))
+        if need_b[i, p]:
+            rec = seq_b[ib]; ib += 1
+            vals = struct.unpack(f"<{ints}i{N}d", rec)
+            assert vals[0] == got["h"][i, p]
+            assert list(vals[1:1 + N]) == list(got["coord"][i, p])
+            assert list(vals[ints:]) == list(got["q"][i, p])
+    assert ib == len(seq_b)
+    # a region that is too small: flagged, dense outputs unaffected
+    small = s.expand_batch_k5(Q, cap_a=64, cap_b=64)
+    assert small["totals"][2] == 1 and np.array_equal(small["flags"], dense["flags"]) and np.array_equal(small["succ_id"], want_id)
+
+
+def test_device_table_on_and_off_give_the_same_search(small_cfg, monkeypatch):
+    """The ids the device table hands back are only a shortcut for the host's own getOrCreateState: the search is the
+    same with SMPLX_DEVICE_TABLE=0 (every lookup on the host) -- and the table survives growing past its first size."""
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    runs = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("SMPLX_DEVICE_TABLE", env)
+        s = capi.Space.from_config(cfg, batch_states=512)
+        s.set_goal_joint(cfg.goal, cfg.goal_tol)
+        s.set_start(cfg.start)
+        runs.append((s.plan(5.0, 1.0, 1.0, True, True, 60000, 60000), s.num_states()))
+    (a, na), (b, nb) = runs
+    assert na == nb and na > (1 << 17)                      # more states than half the initial 2^18 slots: it grew
+    assert a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"]) and np.array_equal(a["path"], b["path"])
