@@ -151,17 +151,18 @@ def main():
     # frontier) and the ballot-compacted successor stream
     rb = space.compact_rec_b_bytes()
     d_id = torch.zeros(B * M, dtype=torch.int32, device=dev)
-    d_reca = torch.zeros(B * M * 2, dtype=torch.int32, device=dev)
-    d_recb = torch.zeros(B * M * rb, dtype=torch.uint8, device=dev)
+    cap_k5 = capi.lib().smplx_compact_capacity(space.h, B)
+    d_reca = torch.zeros(cap_k5 * 2, dtype=torch.int32, device=dev)
+    d_recb = torch.zeros(cap_k5 * rb, dtype=torch.uint8, device=dev)
     d_btab = torch.zeros(space.compact_blocks(B) * 4, dtype=torch.int32, device=dev)
-    d_tot = torch.zeros(4, dtype=torch.int32, device=dev)
+    d_tot = torch.zeros(capi.lib().smplx_compact_totals_len(), dtype=torch.int32, device=dev)
     space.table_sync()
     stream = torch.cuda.current_stream()
 
     def step():
         space.expand_batch_k5_device(d_q.data_ptr(), B, d_flags.data_ptr(), d_coord.data_ptr(), d_sq.data_ptr(),
-                                     d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_id.data_ptr(), d_reca.data_ptr(), B * M,
-                                     d_recb.data_ptr(), B * M, d_btab.data_ptr(), d_tot.data_ptr(), d_work.data_ptr(),
+                                     d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_id.data_ptr(), d_reca.data_ptr(), cap_k5,
+                                     d_recb.data_ptr(), cap_k5, d_btab.data_ptr(), d_tot.data_ptr(), d_work.data_ptr(),
                                      d_cnt.data_ptr(), stream.cuda_stream)
 
     for _ in range(args.warmup):
@@ -182,7 +183,8 @@ def main():
     prep_ms, expand_ms, launches = space.profile_end()
     evals, valid, lookups_ref, lookups_done, configs, state_lookups = space.counters_read(d_cnt.data_ptr(), B)
     elapsed = t1 - t0
-    tot_k5 = d_tot.cpu().numpy()
+    raw_k5 = d_tot.cpu().numpy()
+    tot_k5 = [int(raw_k5[0:-1:32].sum()), int(raw_k5[1:-1:32].sum()), int(raw_k5[-1])]
     known = int((d_id >= 0).sum().item())
     k5 = {"valid_successors_per_launch": int(tot_k5[0]), "full_records_per_launch": int(tot_k5[1]), "overflow": int(tot_k5[2]),
           "known_ids_per_launch": known, "table_states": space.num_states() - 1,

@@ -187,11 +187,19 @@ int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t*
  *             int32 h, int32 coord[nvars], padding to 8 bytes, double q[nvars]
  *   block_tab[4 b .. 4 b + 3] = {first A, count A, first B, count B} of thread block b (smplx_compact_blocks(B) blocks);
  *             walking the blocks in order gives the records in (state, primitive) order
- *   totals[0], totals[1] = records in A, B; totals[2] = 1 if a region was too small (the dense outputs are still complete)
- * smplx_table_sync pushes pending inserts without a batch.  Env SMPLX_DEVICE_TABLE=0 disables the device table. */
+ *   Each region is cut into 16 sub-regions with their own counters (same-address atomics serialise on this chip): on
+ *   the device d_totals has smplx_compact_totals_len() int32 -- [32 k], [32 k + 1] = records of sub-region k in A, B
+ *   (sub-region k starts at k * cap / 16), the last one = 1 if a sub-region was too small (the dense outputs are still
+ *   complete); the host-pointer form returns totals[0], totals[1] = records in A, B and totals[2] = that flag
+ * smplx_table_sync creates the device table if the space has none yet and pushes pending inserts without a batch; so do
+ * the two entry points below.  The searches driven by smplx_plan / smplx_plan_multi / smplx_get_succs use the device
+ * table only with env SMPLX_DEVICE_TABLE=1 (same results either way): at the batch sizes a search produces the ids it
+ * hands back save the host less time than the lookups add to every batch (A/B figures in DESIGN.md section 6). */
 int smplx_table_sync(smplx_space* s);
 size_t smplx_compact_rec_b_bytes(const smplx_space* s);
 int smplx_compact_blocks(const smplx_space* s, int B);
+int smplx_compact_totals_len(void);
+int smplx_compact_capacity(const smplx_space* s, int B);   /* records per region with which no sub-region can overflow */
 /* everything resident in HBM (d_succ_id, and the four compact arguments together, may be NULL); launches on `stream` */
 int smplx_expand_batch_k5_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord, double* d_succ_q,
                                  int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, int32_t* d_succ_id, int32_t* d_rec_a, int cap_a,

@@ -33,6 +33,7 @@ SYMBOLS = [
     "smplx_bfs_metric_goal_distance", "smplx_bfs_metric_start_distance", "smplx_space_status", "smplx_space_clear_status",
     "smplx_check_joint_limits", "smplx_cc_state_valid_batch_device", "smplx_space_counters",
     "smplx_table_sync", "smplx_compact_rec_b_bytes", "smplx_compact_blocks", "smplx_expand_batch_k5_device", "smplx_expand_batch_k5",
+    "smplx_compact_totals_len", "smplx_compact_capacity",
 ]
 
 
@@ -330,8 +331,8 @@ class Space:
     def expand_batch_k5(self, q, cap_a=None, cap_b=None):
         """Dense outputs + device-table ids + the compacted successor stream (decoded into per-state lists)."""
         q = _f64(q).reshape(-1, self.N); B = q.shape[0]; M, N = self.M, self.N
-        cap_a = B * M if cap_a is None else cap_a
-        cap_b = B * M if cap_b is None else cap_b
+        cap_a = lib().smplx_compact_capacity(self.h, B) if cap_a is None else cap_a
+        cap_b = lib().smplx_compact_capacity(self.h, B) if cap_b is None else cap_b
         flags = np.zeros((B, M), np.uint8); coord = np.zeros((B, M, N), np.int32); sq = np.zeros((B, M, N))
         h = np.zeros((B, M), np.int32); sid = np.zeros((B, M), np.int32)
         rb = self.compact_rec_b_bytes(); nb = self.compact_blocks(B)

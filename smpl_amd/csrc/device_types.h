@@ -120,13 +120,18 @@ struct SmplxTableDev {
 // whose own joint values extractPath reports), a record [h, coord[nvars], pad][q[nvars]] in region B.  A block
 // claims one range of each region (wave ballots -> block totals -> one atomic per region), so records appear in
 // (state, primitive) order inside a block; block_tab[4b..4b+3] = {first A, count A, first B, count B} of block b.
-// totals[0] / totals[1] = records in A / B, totals[2] = 1 if a region overflowed (the dense outputs remain valid).
+// Same-address atomics serialise at ~12 ns on this chip (800 blocks on one counter: 19 us measured), so each region is
+// cut into SMPLX_CMP_SHARDS sub-regions with their own counters on separate 128-byte lines; block b claims in shard
+// b % SMPLX_CMP_SHARDS.  totals[32 k] / totals[32 k + 1] = records of shard k in A / B (its sub-region starts at
+// k * cap / SMPLX_CMP_SHARDS); totals[32 * SMPLX_CMP_SHARDS] = 1 if a sub-region overflowed (dense outputs stay valid).
+#define SMPLX_CMP_SHARDS 16
+#define SMPLX_CMP_TOTALS (32 * SMPLX_CMP_SHARDS + 1)
 struct SmplxCompactDev {
     int32_t* rec_a;              // 2 int32 per record
     unsigned char* rec_b;        // rec_b_bytes per record
     int32_t* block_tab;
-    int32_t* totals;             // zeroed by the setup kernel of the same launch sequence
-    int32_t cap_a, cap_b;
+    int32_t* totals;             // SMPLX_CMP_TOTALS int32, zeroed by the first kernel of the same launch sequence
+    int32_t cap_a, cap_b;        // records per region (multiples of SMPLX_CMP_SHARDS)
     int32_t rec_b_bytes, pad;
 };
 

@@ -482,6 +482,27 @@ int table_upload(smplx_space* lead, const std::vector<int32_t>& items, DevBuf<in
     return SMPLX_OK;
 }
 
+// first use of the device table on a space that was created without one (smplx_table_sync, the K5 entry points):
+// allocate it for the states there are and queue them all
+int table_ensure(smplx_space* s)
+{
+    if (s->d_table) return SMPLX_OK;
+    size_t cap = (size_t)1 << 18;
+    const size_t nstates = s->h_of_id.size();
+    while (nstates * 2 > cap) cap *= 4;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (int e = table_alloc(s, cap)) return e;
+    if (int e = upload_space(s)) return e;
+    s->pending_ins.clear();
+    for (int id = 1; id < (int)nstates; ++id) {
+        s->pending_ins.push_back(0);
+        s->pending_ins.push_back(id);
+        s->pending_ins.insert(s->pending_ins.end(), &s->coords[(size_t)id * s->N], &s->coords[(size_t)id * s->N] + s->N);
+    }
+    s->table_count = nstates > 0 ? nstates - 1 : 0;
+    return SMPLX_OK;
+}
+
 // the space's own batches: everything pending goes up on its stream
 int table_flush(smplx_space* s, hipStream_t stream)
 {
@@ -497,7 +518,18 @@ int table_flush(smplx_space* s, hipStream_t stream)
 struct K5Out {
     int32_t* d_id = nullptr;                 // dense [B][M] ids (-1 = unknown)
     const SmplxCompactDev* cmp = nullptr;    // compact stream (device pointers), or null
+    const int32_t* items = nullptr;          // states to insert at the head of the batch's first kernel: n_items x (N + 2)
+    int n_items = 0;                         //   int32 (device memory, or pinned host memory for the zero-copy launch)
 };
+
+// The pending inserts of a batch travel in the same upload as its parents: they sit behind the B x N doubles of the
+// pinned parent buffer.  Returns the doubles the items occupy; *items_at = their offset in doubles.
+size_t stage_items(PinBuf<double>& p_q, size_t parent_doubles, const std::vector<int32_t>& items)
+{
+    if (items.empty()) return 0;
+    std::memcpy((void*)(p_q.p + parent_doubles), items.data(), items.size() * sizeof(int32_t));
+    return (items.size() + 1) / 2;
+}
 
 // pinned host buffers of a zero-copy small batch: the kernel reads the parents from, and also writes the results to, host
 // memory (a few KB of PCIe traffic instead of DMA copies with their fixed latency)
@@ -529,6 +561,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     std::memset(&cmp, 0, sizeof(cmp));
     if (k5 && k5->cmp) cmp = *k5->cmp;
     if (cmp.rec_a) force_pipeline = true;   // the compact stream is produced by k_pipe_finish
+    const int32_t* ins_items = k5 && s->d_table ? k5->items : nullptr;
+    const int n_ins = ins_items ? k5->n_items : 0;
     if (s->tiny_work_list) k.capacity = 8 * 16;   // test hook: almost every edge overflows into the deferred pass
     hipEvent_t* ev = nullptr;
     if (s->prof_used + 3 <= s->prof_events.size()) { ev = &s->prof_events[s->prof_used]; s->prof_used += 3; }
@@ -543,14 +577,17 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         // a handful of states: ONE launch, all FK chains side by side (kernels.hip k_small_batch)
         // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
         const double* qsrc = zero_copy ? zero_copy->q : d_q;
-        KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
+        KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B + blocks_for(n_ins, small_block)), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
                            zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
                            zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
-                           zero_copy ? zero_copy->id : (int32_t*)nullptr);
+                           zero_copy ? zero_copy->id : (int32_t*)nullptr, ins_items, n_ins);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (d_id) HIP_TRY(hipMemsetAsync(d_id, 0xFF, sizeof(int32_t) * (size_t)B * s->M, stream));   // fused mode: no table lookups
+        if (n_ins > 0) {
+            hipLaunchKernelGGL(k_table_insert, dim3(blocks_for(n_ins, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), 0, stream, s->d_space, stab, ins_items, n_ins, s->N);
+        }
         if (ev) (void)hipEventRecord(ev[0], stream);
         KLAUNCH(s, K_STATE_PREP, k_state_prep, dim3(bs), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, k.state_bad, k.state_lookups, stab, state_q);
@@ -562,8 +599,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     } else {
         const size_t lm = s->blob_bytes;
         ++s->pipe_launches;
-        KLAUNCH(s, K_PIPE_PREP, k_pipe_prep, dim3(bs), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
-                           k.goal_dist, k.work_count, stab, state_q, cmp.totals);
+        KLAUNCH(s, K_PIPE_PREP, k_pipe_prep, dim3(bs + blocks_for(n_ins, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
+                           k.goal_dist, k.work_count, stab, state_q, cmp.totals, ins_items, n_ins);
         KLAUNCH(s, K_PIPE_SETUP, k_pipe_setup, dim3(be), dim3(SMPLX_BLOCK), lm, stream, s->d_space, d_q, norefs, B,
                            k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
                            k.work, k.work_count, k.capacity, stab, state_q);
@@ -756,10 +793,24 @@ int issue_batch(smplx_space* s, int id)
     s->inflight_zero_copy = takes_small_kernel(s, B);
     s->inflight_small = s->inflight_zero_copy;
     s->t_issue = std::chrono::steady_clock::now();
-    if ((e = table_flush(s, s->stream))) return e;   // states committed since the last batch join the device table
+    // K5: the states committed since the last batch join the device table at the head of this batch's first kernel;
+    // their (id, coordinate) triples ride in the parents' upload
     K5Out k5;
     k5.d_id = s->dv.id;
+    size_t item_doubles = 0;
+    if (s->d_table) {
+        if ((e = table_grow_if_needed(s))) return e;
+        if (!s->pending_ins.empty()) {
+            if ((e = s->p_q.reserve((size_t)B * N + s->pending_ins.size() / 2 + 1))) return e;
+            if ((e = s->b_q.reserve((size_t)B * N + s->pending_ins.size() / 2 + 1))) return e;
+            for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);   // the buffer may have moved
+            k5.n_items = (int)(s->pending_ins.size() / ((size_t)N + 2));
+            item_doubles = stage_items(s->p_q, (size_t)B * N, s->pending_ins);
+            s->pending_ins.clear();
+        }
+    }
     if (s->inflight_zero_copy) {
+        k5.items = (const int32_t*)(s->p_q.p + (size_t)B * N);
         ZeroCopy zc;
         zc.q = s->p_q.p; zc.flags = s->pv.flags; zc.coord = s->pv.coord; zc.sq = s->pv.sq; zc.h = s->pv.h; zc.id = s->pv.id;
         if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
@@ -768,7 +819,8 @@ int issue_batch(smplx_space* s, int id)
         ++s->gpu_batches;
         return SMPLX_OK;
     }
-    HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * B * N, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * ((size_t)B * N + item_doubles), hipMemcpyHostToDevice, s->stream));
+    k5.items = (const int32_t*)(s->b_q.p + (size_t)B * N);
     if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
                            s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, nullptr, false, &k5))) return e;
     HIP_TRY(hipMemcpyAsync(s->p_out.p, s->b_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));   // one copy for all five outputs
@@ -1088,9 +1140,12 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     hipLaunchKernelGGL(k_bfs_init, dim3(2048), dim3(256), 0, s->stream, grid->dev, s->wall_thr, dx, dy, dz, s->d_bfs);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_bfs_init");
     {
-        // device copy of the state table (K5); SMPLX_DEVICE_TABLE=0 keeps every lookup on the host
+        // Device copy of the state table (K5).  The K5 entry points and smplx_table_sync create it on first use.  The
+        // planner's own batches use it only with SMPLX_DEVICE_TABLE=1: measured on MI355X (cfg 2 / cfg 4, bench.py) the
+        // ids it hands back save the host ~0.5 us per expansion, but the lookups and the rides of the inserts add more
+        // than that to the latency of every batch (single query 79k -> 70k states/s, 128-query shard 1.26M -> 1.03M).
         const char* env = getenv("SMPLX_DEVICE_TABLE");
-        if (!(env && env[0] == '0') && table_alloc(s, (size_t)1 << 18) != SMPLX_OK) {
+        if (env && env[0] == '1' && table_alloc(s, (size_t)1 << 18) != SMPLX_OK) {
             const std::string m = g_error; smplx_space_destroy(s); return set_error(SMPLX_E_HIP, m);
         }
     }
@@ -1405,6 +1460,7 @@ int smplx_expand_batch_device(smplx_space* s, const double* d_q, int B, uint8_t*
 int smplx_table_sync(smplx_space* s)
 {
     if (!s) return set_error(SMPLX_E_ARG, "null argument");
+    if (int e = table_ensure(s)) return e;
     if (int e = table_flush(s, s->stream)) return e;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return SMPLX_OK;
@@ -1412,6 +1468,13 @@ int smplx_table_sync(smplx_space* s)
 
 size_t smplx_compact_rec_b_bytes(const smplx_space* s) { return s ? (size_t)smplx_rec_b_bytes(s->N) : 0; }
 int smplx_compact_blocks(const smplx_space* s, int B) { return s && B > 0 ? blocks_for((long long)B * s->M, SMPLX_BLOCK) : 0; }
+int smplx_compact_totals_len(void) { return SMPLX_CMP_TOTALS; }
+int smplx_compact_capacity(const smplx_space* s, int B)
+{
+    if (!s || B <= 0) return 0;
+    const int nblocks = blocks_for((long long)B * s->M, SMPLX_BLOCK);
+    return SMPLX_CMP_SHARDS * ((nblocks + SMPLX_CMP_SHARDS - 1) / SMPLX_CMP_SHARDS) * SMPLX_BLOCK;   // no sub-region can overflow
+}
 
 int smplx_expand_batch_k5_device(smplx_space* s, const double* d_q, int B, uint8_t* d_flags, int32_t* d_coord, double* d_succ_q,
                                  int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, int32_t* d_succ_id, int32_t* d_rec_a, int cap_a,
@@ -1420,7 +1483,10 @@ int smplx_expand_batch_k5_device(smplx_space* s, const double* d_q, int B, uint8
 {
     if (!s || !d_q || !d_flags || !d_coord || !d_succ_q || !d_h || !d_cost || !d_lookups || !d_work || B <= 0)
         return set_error(SMPLX_E_ARG, "bad argument");
-    if (d_rec_a && (!d_rec_b || !d_block_tab || !d_totals || cap_a <= 0 || cap_b <= 0)) return set_error(SMPLX_E_ARG, "incomplete compact-stream arguments");
+    if (d_rec_a && (!d_rec_b || !d_block_tab || !d_totals || cap_a < SMPLX_CMP_SHARDS || cap_b < SMPLX_CMP_SHARDS))
+        return set_error(SMPLX_E_ARG, "incomplete compact-stream arguments");
+    cap_a = cap_a / SMPLX_CMP_SHARDS * SMPLX_CMP_SHARDS;
+    cap_b = cap_b / SMPLX_CMP_SHARDS * SMPLX_CMP_SHARDS;
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "set a goal first");
     if (s->fused_mode && d_rec_a) return set_error(SMPLX_E_STATE, "the compact stream needs the pipeline kernels (not fused mode)");
     SmplxCompactDev cmp;
@@ -1446,8 +1512,9 @@ int smplx_expand_batch_k5(smplx_space* s, const double* q, int B, uint8_t* flags
     const int nblocks = blocks_for((long long)BM, SMPLX_BLOCK);
     int e;
     if ((e = s->b_way.reserve(BM))) return e;                                       // dense ids
-    if ((e = s->b_ins.reserve(2 * (size_t)cap_a + 4 * (size_t)nblocks + 4))) return e;   // A records | block table | totals
+    if ((e = s->b_ins.reserve(2 * (size_t)cap_a + 4 * (size_t)nblocks + SMPLX_CMP_TOTALS))) return e;   // A records | block table | totals
     if ((e = s->b_out.reserve(rb * (size_t)cap_b))) return e;                       // B records
+    if ((e = table_ensure(s))) return e;
     if ((e = table_flush(s, s->stream))) return e;
     int32_t* d_a = s->b_ins.p;
     int32_t* d_bt = d_a + 2 * (size_t)cap_a;
@@ -1463,8 +1530,12 @@ int smplx_expand_batch_k5(smplx_space* s, const double* q, int B, uint8_t* flags
     HIP_TRY(hipMemcpyAsync(rec_a, d_a, sizeof(int32_t) * 2 * (size_t)cap_a, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(rec_b, s->b_out.p, rb * (size_t)cap_b, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(block_tab, d_bt, sizeof(int32_t) * 4 * (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(totals, d_tot, sizeof(int32_t) * 3, hipMemcpyDeviceToHost, s->stream));
+    int32_t raw[SMPLX_CMP_TOTALS];
+    HIP_TRY(hipMemcpyAsync(raw, d_tot, sizeof(raw), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    totals[0] = totals[1] = 0;
+    for (int k = 0; k < SMPLX_CMP_SHARDS; ++k) { totals[0] += raw[32 * k]; totals[1] += raw[32 * k + 1]; }
+    totals[2] = raw[32 * SMPLX_CMP_SHARDS];
     return SMPLX_OK;
 }
 
@@ -1933,19 +2004,33 @@ int run_group(smplx_space** spaces, Search* S, int q0, int q1, char* done, doubl
             }
             const auto tp1 = now();
             t_pack += secs(tr1, tp1);
-            {
+            K5Out k5;
+            k5.d_id = lead->dv.id;
+            size_t item_doubles = 0;
+            if (lead->d_table) {
                 std::vector<int32_t>& items = ins_items;
                 items.clear();
                 for (int q : reqs) {
                     if ((e = table_grow_if_needed(spaces[q]))) return e;
                     table_take_pending(spaces[q], q - q0, items);
                 }
-                if ((e = table_upload(lead, items, lead->b_ins, lead->p_ins, lead->stream, lead->b_stab.p))) return e;
+                if (!items.empty()) {
+                    if ((e = lead->p_q.reserve(total * N + items.size() / 2 + 1))) return e;   // (may move the buffer: packed below)
+                    if ((e = lead->b_q.reserve(total * N + items.size() / 2 + 1))) return e;
+                    k5.n_items = (int)(items.size() / ((size_t)N + 2));
+                }
             }
-            HIP_TRY(hipMemcpyAsync(lead->b_q.p, lead->p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, lead->stream));
+            {   // parents (packed again here: the pinned buffer may just have been re-allocated)
+                size_t r2 = 0;
+                for (int q : reqs) {
+                    const smplx_space* sq = spaces[q];
+                    for (int32_t id : sq->inflight) { std::memcpy(&lead->p_q.p[r2 * N], &sq->qs[(size_t)id * N], sizeof(double) * N); ++r2; }
+                }
+                item_doubles = stage_items(lead->p_q, total * N, ins_items);
+            }
+            HIP_TRY(hipMemcpyAsync(lead->b_q.p, lead->p_q.p, sizeof(double) * (total * N + item_doubles), hipMemcpyHostToDevice, lead->stream));
             HIP_TRY(hipMemcpyAsync(lead->b_stateq.p, lead->p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, lead->stream));
-            K5Out k5;
-            k5.d_id = lead->dv.id;
+            k5.items = (const int32_t*)(lead->b_q.p + total * N);
             if ((e = launch_expand(lead, lead->b_q.p, B, lead->dv.flags, lead->dv.coord, lead->dv.sq, lead->dv.h, lead->b_cost.p,
                                    lead->b_lookups.p, lead->b_work.p, nullptr, lead->stream, lead->b_stab.p, lead->b_stateq.p,
                                    nullptr, false, &k5))) return e;
@@ -2155,9 +2240,21 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         table_take_pending(sq, q, Nf.ins_items);
                         qstate[q].store(QS_IN_FLIGHT, std::memory_order_relaxed);
                     }
-                    if ((e = table_upload(lead, Nf.ins_items, Nf.b_ins, Nf.p_ins, Nf.stream, lead->b_stab.p))) return e;
                     K5Out k5;
                     k5.d_id = Nf.dv.id;
+                    size_t item_doubles = 0;
+                    if (!Nf.ins_items.empty()) {
+                        const size_t need = total * N + Nf.ins_items.size() / 2 + 1;
+                        if (need > Nf.p_q.cap) {   // re-allocate and pack the parents again
+                            if ((e = Nf.p_q.reserve(need))) return e;
+                            size_t r2 = 0;
+                            for (int q : Nf.queries)
+                                for (int32_t id : spaces[q]->inflight) { std::memcpy(&Nf.p_q.p[r2 * N], &spaces[q]->qs[(size_t)id * N], sizeof(double) * N); ++r2; }
+                        }
+                        if ((e = Nf.b_q.reserve(need))) return e;
+                        k5.n_items = (int)(Nf.ins_items.size() / ((size_t)N + 2));
+                        item_doubles = stage_items(Nf.p_q, total * N, Nf.ins_items);
+                    }
                     // rocprofv3 on MI355X, 128 queries: the single-launch kernel with its results written straight to host
                     // memory averages 152 us at ~100 states (it is built for the handful of states a lone query misses
                     // on: 33 us), the four pipeline kernels together 36 us
@@ -2165,11 +2262,13 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         // one launch, no copies: parents, query indices and results live in pinned host memory
                         ZeroCopy zc;
                         zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h; zc.id = Nf.pv.id;
+                        k5.items = (const int32_t*)(Nf.p_q.p + total * N);
                         if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
                                                Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.p_stateq.p, &zc, false, &k5))) return e;
                     } else {
-                        HIP_TRY(hipMemcpyAsync(Nf.b_q.p, Nf.p_q.p, sizeof(double) * total * N, hipMemcpyHostToDevice, Nf.stream));
+                        HIP_TRY(hipMemcpyAsync(Nf.b_q.p, Nf.p_q.p, sizeof(double) * (total * N + item_doubles), hipMemcpyHostToDevice, Nf.stream));
                         HIP_TRY(hipMemcpyAsync(Nf.b_stateq.p, Nf.p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, Nf.stream));
+                        k5.items = (const int32_t*)(Nf.b_q.p + total * N);
                         if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
                                                Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, true, &k5))) return e;
                         HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));

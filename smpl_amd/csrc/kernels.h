@@ -35,7 +35,8 @@ __global__ void k_expand(const SmplxSpaceDev* S, const double* Q, const int64_t*
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q);
 __global__ void k_pipe_prep(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist,
                             int* work_count,
-                         const SmplxSpaceDev* const* stab, const unsigned short* state_q, int* cmp_totals);
+                         const SmplxSpaceDev* const* stab, const unsigned short* state_q, int* cmp_totals,
+                            const int* ins_items, int n_ins);
 __global__ void k_pipe_setup(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, const double* goal_dist,
                              unsigned char* out_flags, double* out_q, int* edge_w, int* edge_lookups,
                              unsigned char* edge_bad, int* state_lookups, unsigned char* state_bad, unsigned long long* work,
@@ -54,7 +55,8 @@ __global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int
                               unsigned char* state_bad_out, int* state_lookups_out, unsigned char* out_flags, int* out_coord,
                               double* out_q, int* out_h, int* out_cost, int* out_lookups, int* deferred_count,
                               const SmplxSpaceDev* const* stab, const unsigned short* state_q, unsigned char* host_flags,
-                              int* host_coord, double* host_q, int* host_h, int* out_id, int* host_id);
+                              int* host_coord, double* host_q, int* host_h, int* out_id, int* host_id, const int* ins_items,
+                              int n_ins);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

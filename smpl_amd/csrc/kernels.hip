@@ -851,19 +851,75 @@ __device__ __forceinline__ int var_to_coord(const ModelLds* __restrict__ M, int 
 
 // ManipLattice::getHashEntry (manip_lattice.cpp:1302-1316) against the device copy of the state table: state id of a
 // discretised coordinate, -1 if the host has not committed it (yet)
+// Inserts of the same launch may still be running (they ride at the head of the batch's first kernel): a slot whose tag
+// is negative is being filled.  No slot between a coordinate's home and its own slot can have been empty since it was
+// inserted, so meeting an empty or a busy slot first means the coordinate was not in the table before this launch.
 __device__ __forceinline__ int table_lookup(const SmplxTableDev& T, const int* __restrict__ c, int nv)
 {
     if (!T.slots) return -1;
     unsigned int i = smplx_coord_hash(c, nv) & T.mask;
     while (true) {
         const int* sl = T.slots + (size_t)i * T.stride;
-        const int tag = sl[0];
-        if (tag == 0) return -1;
+        const int tag = __atomic_load_n(&sl[0], __ATOMIC_RELAXED);
+        if (tag <= 0) return -1;
         bool same = true;
         for (int v = 0; v < nv; ++v) same = same && sl[1 + v] == c[v];
         if (same) return tag - 1;
         i = (i + 1) & T.mask;
     }
+}
+
+// ManipLattice::createHashEntry (manip_lattice.cpp:1318-1354), device side: the host assigns ids in commit order and
+// sends the (query, id, coordinate) triples of the states created since the last batch; a slot is claimed with one CAS
+// on its tag and filled afterwards (lookups run in later launches of the same stream).  items: n x (nvars + 2) int32.
+__device__ __forceinline__ void table_insert_item(const SmplxSpaceDev* __restrict__ S, const SmplxSpaceDev* const* __restrict__ stab,
+                                                  const int* __restrict__ it, int nvars)
+{
+    const SmplxTableDev T = (stab ? stab[it[0]] : S)->table;
+    if (!T.slots) return;
+    const int id = it[1];
+    int c[SMPLX_MAX_VARS];
+    for (int v = 0; v < nvars; ++v) c[v] = it[2 + v];   // the items may live in pinned host memory: read them once
+    unsigned int k = smplx_coord_hash(c, nvars) & T.mask;
+    while (true) {
+        int* sl = T.slots + (size_t)k * T.stride;
+        // claim with a negative ("busy") tag, fill, publish: a concurrent lookup never sees a half-written slot as a hit
+        if (atomicCAS(&sl[0], 0, -(id + 1)) == 0) {
+            for (int v = 0; v < nvars; ++v) sl[1 + v] = c[v];
+            __threadfence();
+            __atomic_store_n(&sl[0], id + 1, __ATOMIC_RELAXED);
+            return;
+        }
+        k = (k + 1) & T.mask;
+    }
+}
+
+// bulk inserts (k_table_insert): every thread of the launch takes its share
+__device__ __forceinline__ void table_insert_items(const SmplxSpaceDev* __restrict__ S, const SmplxSpaceDev* const* __restrict__ stab,
+                                                   const int* __restrict__ items, int n, int nvars)
+{
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) table_insert_item(S, stab, items + (size_t)i * (nvars + 2), nvars);
+}
+
+// The inserts that ride with a batch's first kernel take EXTRA blocks behind the `first_block` working ones, so they run
+// beside the batch instead of in front of it (a lookup that misses one of them just reports "unknown").  Returns true
+// for such a block: the caller returns at once.
+__device__ __forceinline__ bool table_insert_block(const SmplxSpaceDev* __restrict__ S, const SmplxSpaceDev* const* __restrict__ stab,
+                                                   const int* __restrict__ items, int n, int first_block)
+{
+    if ((int)blockIdx.x < first_block) return false;
+    const int i = ((int)blockIdx.x - first_block) * (int)blockDim.x + (int)threadIdx.x;
+    const int nvars = S->model.nvars;
+    if (i < n) table_insert_item(S, stab, items + (size_t)i * (nvars + 2), nvars);
+    return true;
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+k_table_insert(const SmplxSpaceDev* __restrict__ S, const SmplxSpaceDev* const* __restrict__ stab, const int* __restrict__ items,
+               int n, int nvars)
+{
+    table_insert_items(S, stab, items, n, nvars);
 }
 
 // Cooperative copy of the packed model (a few KB) into LDS in 16-byte pieces, all loads of a thread issued before
@@ -1194,15 +1250,19 @@ k_expand(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, cons
 extern "C" __global__ void __launch_bounds__(BLOCK)
 k_pipe_prep(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
             double* __restrict__ goal_dist, int* __restrict__ work_count,
-        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q, int* __restrict__ cmp_totals)
+        const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q, int* __restrict__ cmp_totals,
+            const int* __restrict__ ins_items, int n_ins)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    // K5: the states the host committed since the last batch join the device table (createHashEntry) in extra blocks
+    if (n_ins > 0 && table_insert_block(S, stab, ins_items, n_ins, (B + BLOCK - 1) / BLOCK)) return;
     const ModelLds Mv = setup_model_only(S, smem);
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i <= SMPLX_WORK_SHARDS) work_count[i * SMPLX_SHARD_STRIDE] = 0;   // shard counters + deferred count
-    if (cmp_totals && i < 4) cmp_totals[i] = 0;                          // compaction counters of k_pipe_finish
+    if (cmp_totals && blockIdx.x == 0)                                   // compaction counters of k_pipe_finish
+        for (int k = threadIdx.x; k < SMPLX_CMP_TOTALS; k += BLOCK) cmp_totals[k] = 0;
     if (i >= B) return;
     const SmplxBfsDev bfs = (stab ? stab[state_q[i]] : S)->bfs;
     const double* q = Q + (refs ? refs[i] : (int64_t)i) * MV_NVARS(M);
@@ -1502,9 +1562,12 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             int ta = 0, tb = 0;
 #pragma unroll
             for (int k = 0; k < BLOCK / 64; ++k) { ta += c_cnt[k][0]; tb += c_cnt[k][1]; }
-            int ba = ta > 0 ? atomicAdd(&cmp.totals[0], ta) : 0;
-            const int bb = tb > 0 ? atomicAdd(&cmp.totals[1], tb) : 0;
-            if (ba + ta > cmp.cap_a || bb + tb > cmp.cap_b) { cmp.totals[2] = 1; ba = -1; }   // overflow: dense outputs stay valid
+            const int shard = blockIdx.x % SMPLX_CMP_SHARDS;
+            const int sa = cmp.cap_a / SMPLX_CMP_SHARDS, sb = cmp.cap_b / SMPLX_CMP_SHARDS;
+            int ba = ta > 0 ? atomicAdd(&cmp.totals[32 * shard], ta) : 0;
+            int bb = tb > 0 ? atomicAdd(&cmp.totals[32 * shard + 1], tb) : 0;
+            if (ba + ta > sa || bb + tb > sb) { cmp.totals[32 * SMPLX_CMP_SHARDS] = 1; ba = -1; }   // overflow: dense outputs stay valid
+            else { ba += shard * sa; bb += shard * sb; }
             c_base[0] = ba; c_base[1] = bb;
             int* bt = cmp.block_tab + 4 * (size_t)blockIdx.x;
             bt[0] = ba; bt[1] = ta; bt[2] = bb; bt[3] = tb;
@@ -1555,7 +1618,8 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups, int* __restrict__ deferred_count,
               const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
               unsigned char* __restrict__ host_flags, int* __restrict__ host_coord, double* __restrict__ host_q,
-              int* __restrict__ host_h, int* __restrict__ out_id, int* __restrict__ host_id)
+              int* __restrict__ host_h, int* __restrict__ out_id, int* __restrict__ host_id,
+              const int* __restrict__ ins_items, int n_ins)
 {
     // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
     // as a few KB of PCIe stores than as four DMA copies); Q may itself be pinned host memory -- the parent's
@@ -1564,6 +1628,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     __shared__ double s_goal_dist;
     __shared__ int s_state_bad, s_state_lookups;
     __shared__ double s_parent[SMPLX_MAX_VARS];
+    if (n_ins > 0 && table_insert_block(S, stab, ins_items, n_ins, B)) return;   // K5: see k_pipe_prep
     const int nth = blockDim.x;
     ModelLds Mv;
     ThreadLds L = setup_lds(S, smem, &Mv, nth);
@@ -1653,7 +1718,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 
     // ---- lanes 0..6: one waypoint each; lane 7: the successor's bookkeeping ----
     int my_bad = 0, my_lk = 0;
-    int h = 0, is_goal = 0;
+    int h = 0, is_goal = 0, early_id = -1;
     if (edge_thread && have_action && limits_ok) {
         if (slot < SMPLX_SMALL_LANES - 1) {
             // waypoints slot+1, slot+8, ...: an edge longer than 7 waypoints wraps around its lanes
@@ -1682,6 +1747,9 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             int c[3];
             world_to_cell(grid, p, c);
             h = bfs_cost_to_goal(bfs, c);
+            // K5: the table lookup only needs the coordinates: issued here, it lands while the lanes of the edge and the
+            // state's own check are still working
+            if (out_id) early_id = table_lookup(Sq->table, sc, nv);
         }
     }
     __syncthreads();   // the state's own check and the goal distance have landed in LDS
@@ -1716,7 +1784,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         out_lookups[eid] = lookups;
         int sid = -1;
         if (out_id) {   // K5: device copy of the state table (see k_pipe_finish)
-            if (flags & SMPLX_F_VALID) sid = table_lookup(Sq->table, out_coord + eid * nv, nv);
+            if (flags & SMPLX_F_VALID) sid = early_id;
             out_id[eid] = sid;
         }
         if (host_flags) {
@@ -1784,31 +1852,6 @@ k_heuristic(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, i
     world_to_cell(S->grid, p, c);
     out_h[i] = bfs_cost_to_goal(S->bfs, c);
     if (out_xyz) { out_xyz[3 * i] = p[0]; out_xyz[3 * i + 1] = p[1]; out_xyz[3 * i + 2] = p[2]; }
-}
-
-// ManipLattice::createHashEntry (manip_lattice.cpp:1318-1354), device side: the host assigns ids in commit order and
-// sends the (query, id, coordinate) triples of the states created since the last batch; a slot is claimed with one CAS
-// on its tag and filled afterwards (lookups run in later launches of the same stream).  items: n x (nvars + 2) int32.
-extern "C" __global__ void __launch_bounds__(BLOCK)
-k_table_insert(const SmplxSpaceDev* __restrict__ S, const SmplxSpaceDev* const* __restrict__ stab, const int* __restrict__ items,
-               int n, int nvars)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int* it = items + (size_t)i * (nvars + 2);
-    const SmplxTableDev T = (stab ? stab[it[0]] : S)->table;
-    if (!T.slots) return;
-    const int id = it[1];
-    const int* c = it + 2;
-    unsigned int k = smplx_coord_hash(c, nvars) & T.mask;
-    while (true) {
-        int* sl = T.slots + (size_t)k * T.stride;
-        if (atomicCAS(&sl[0], 0, id + 1) == 0) {
-            for (int v = 0; v < nvars; ++v) sl[1 + v] = c[v];
-            return;
-        }
-        k = (k + 1) & T.mask;
-    }
 }
 
 // BfsHeuristic::getMetricGoalDistance (bfs_heuristic.cpp:129-138) for a batch of workspace points
