@@ -53,6 +53,24 @@ int smplx_grid_create(const double origin[3], int nx, int ny, int nz, double res
                       const int32_t* d2, smplx_grid** out);
 void smplx_grid_destroy(smplx_grid* g);
 
+/* ---- voxel grid, construction side -----------------------------------------------------------------
+ * OccupancyGrid::addPointsToField / removePointsFromField (smpl/src/occupancy_grid.cpp:357-422) over
+ * DistanceMap::addPointsToMap / removePointsFromMap (distance_map.hpp:306-435): the field is built and kept on the
+ * GPU.  Specified as the EXACT Euclidean transform with the reference's cap (ceil(max_dist/res) cells) and border rule
+ * (the one-cell layer around the grid is occupied): d2 = min(dmax^2, min over occupied/border cells of |c - o|^2).
+ * The reference's own bucketed propagation (distance_map.hpp:627-839) depends on its pop order where distances tie and
+ * cannot be compiled here (Eigen): parity with it is unpinned; exactness is tested against brute force.
+ * Every change recomputes the whole field (three separable passes: milliseconds at 256^3). */
+int smplx_grid_create_empty(const double origin[3], int nx, int ny, int nz, double res, double max_dist, smplx_grid** out);
+/* boxes: n x {cx, cy, cz, sx, sy, sz} (world metres), the objects of a scene file (smpl_test/src/call_planner.cpp:158-207):
+ * a box occupies the cells from the cell of its low corner to the cell of its high corner */
+int smplx_grid_add_boxes(smplx_grid* g, const double* boxes, int n);
+/* xyz: n world points (voxel centres); points outside the grid are skipped (distance_map.hpp:312-316) */
+int smplx_grid_add_points(smplx_grid* g, const double* xyz, int n);
+int smplx_grid_remove_points(smplx_grid* g, const double* xyz, int n);
+/* the field as smplx_grid_create takes it: d2[nx*ny*nz], x-major, z fastest */
+int smplx_grid_copy_d2(const smplx_grid* g, int32_t* d2);
+
 /* ---- robot model --------------------------------------------------------------------------
  * RobotCollisionModel (sbpl_collision_checking/src/robot_collision_model.cpp:117-623),
  * sphere trees (base_collision_models.cpp:337-444), RobotMotionCollisionModel

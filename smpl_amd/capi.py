@@ -34,6 +34,7 @@ SYMBOLS = [
     "smplx_check_joint_limits", "smplx_cc_state_valid_batch_device", "smplx_space_counters",
     "smplx_table_sync", "smplx_compact_rec_b_bytes", "smplx_compact_blocks", "smplx_expand_batch_k5_device", "smplx_expand_batch_k5",
     "smplx_compact_totals_len", "smplx_compact_capacity",
+    "smplx_grid_create_empty", "smplx_grid_add_boxes", "smplx_grid_add_points", "smplx_grid_remove_points", "smplx_grid_copy_d2",
 ]
 
 
@@ -120,6 +121,44 @@ class Grid:
         assert d2.shape == tuple(dims)
         _chk(lib().smplx_grid_create(_p(o, _dp), dims[0], dims[1], dims[2], res, max_dist, _p(d2, _ip), C.byref(self.h)))
         self.dims = tuple(dims)
+
+    @classmethod
+    def empty(cls, origin, dims, res, max_dist):
+        """A grid built and kept on the GPU (row N1): starts empty (only the border cells count as obstacles)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        o = _f64(origin)
+        lib().smplx_grid_create_empty.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+        _chk(lib().smplx_grid_create_empty(_p(o, _dp), dims[0], dims[1], dims[2], res, max_dist, C.byref(self.h)))
+        self.dims = tuple(dims)
+        return self
+
+    @classmethod
+    def from_boxes(cls, origin, dims, res, max_dist, boxes):
+        self = cls.empty(origin, dims, res, max_dist)
+        self.add_boxes(boxes)
+        return self
+
+    def add_boxes(self, boxes):
+        b = _f64([list(c) + list(s) for (c, s) in boxes]).reshape(-1, 6)
+        lib().smplx_grid_add_boxes.argtypes = [C.c_void_p, _dp, C.c_int]
+        _chk(lib().smplx_grid_add_boxes(self.h, _p(b, _dp), b.shape[0]))
+
+    def add_points(self, xyz):
+        p = _f64(xyz).reshape(-1, 3)
+        lib().smplx_grid_add_points.argtypes = [C.c_void_p, _dp, C.c_int]
+        _chk(lib().smplx_grid_add_points(self.h, _p(p, _dp), p.shape[0]))
+
+    def remove_points(self, xyz):
+        p = _f64(xyz).reshape(-1, 3)
+        lib().smplx_grid_remove_points.argtypes = [C.c_void_p, _dp, C.c_int]
+        _chk(lib().smplx_grid_remove_points(self.h, _p(p, _dp), p.shape[0]))
+
+    def d2(self):
+        out = np.zeros(self.dims, np.int32)
+        lib().smplx_grid_copy_d2.argtypes = [C.c_void_p, _ip]
+        _chk(lib().smplx_grid_copy_d2(self.h, _p(out, _ip)))
+        return out
 
     def close(self):
         if self.h:

@@ -173,14 +173,7 @@ inline OutView carve_out(unsigned char* base, size_t BM, int N)
 
 }  // namespace
 
-struct smplx_grid {
-    SmplxGridDev dev;
-    uint16_t* d_d2 = nullptr;
-    double origin[3];
-    double res, max_dist;
-    int n[3];
-    int dmax_int, dmax_sqrd;
-};
+#include "grid_handle.h"
 
 struct smplx_model {
     smplx::HostModel hm;
@@ -985,8 +978,13 @@ void smplx_grid_destroy(smplx_grid* g)
 {
     if (!g) return;
     if (g->d_d2) (void)hipFree(g->d_d2);
+    if (g->d_occ) (void)hipFree(g->d_occ);
+    if (g->d_tmp) (void)hipFree(g->d_tmp);
     delete g;
 }
+
+// error text for the other translation units of the library (field.hip)
+int smplx_internal_set_error(int code, const char* msg) { return set_error(code, msg ? msg : ""); }
 
 int smplx_model_create(const char* robot_text, smplx_model** out)
 {

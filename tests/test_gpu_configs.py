@@ -145,6 +145,11 @@ def test_config5_dual_arm_512cube():
     _need_gpu()
     cfg = scenes.config5()
     assert cfg.grid.dims == (512, 512, 512) and cfg.grid.res == 0.01
+    # row N1 at this size: the field built on the GPU from the box list equals the host builder's
+    gr = cfg.grid
+    built = capi.Grid.from_boxes(gr.origin, gr.dims, gr.res, gr.max_dist, cfg.boxes)
+    assert np.array_equal(built.d2(), gr.d2)
+    del built
     s = capi.Space.from_config(cfg, batch_states=4096)
     assert (s.model.nvars, s.model.ntrees, s.model.npairs, s.M) == (14, 16, 85, 59)
     s.set_goal_joint(cfg.goal, cfg.goal_tol)
