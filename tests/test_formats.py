@@ -41,3 +41,70 @@ def test_sphere_lines_from_the_reference_collision_yaml():
     assert len(lines) == 5 and lines[1].startswith("sphere upper_arm_link rua0 0.18 0.0 -0.015 0.11 4")
     everything = formats.sphere_lines_from_collision_yaml(open(REF_YAML).read())
     assert len(everything) > 60
+
+
+ARM_URDF = """<?xml version="1.0"?>
+<robot name="arm3">
+  <link name="base_link"/><link name="l1"/><link name="l2"/><link name="l3"/><link name="tool"/>
+  <link name="head"/><link name="cam"/>
+  <joint name="j1" type="revolute"><parent link="base_link"/><child link="l1"/>
+    <origin xyz="0 0 0.3" rpy="0 0 0.5"/><axis xyz="0 0 1"/><limit lower="-1.5" upper="1.5" effort="1" velocity="1"/></joint>
+  <joint name="j2" type="continuous"><parent link="l1"/><child link="l2"/><origin xyz="0.25 0 0"/><axis xyz="0 1 0"/></joint>
+  <joint name="j3" type="prismatic"><parent link="l2"/><child link="l3"/><origin xyz="0.2 0 0" rpy="0 1.5707963267948966 0"/>
+    <axis xyz="0 0 1"/><limit lower="0" upper="0.2"/></joint>
+  <joint name="jt" type="fixed"><parent link="l3"/><child link="tool"/><origin xyz="0 0 0.1"/></joint>
+  <joint name="neck" type="revolute"><parent link="base_link"/><child link="head"/><origin xyz="0 0 1"/><axis xyz="0 0 1"/>
+    <limit lower="-1" upper="1"/></joint>
+  <joint name="camj" type="fixed"><parent link="head"/><child link="cam"/></joint>
+</robot>
+"""
+
+
+def test_urdf_subset_reader_produces_a_model_the_host_compiler_accepts():
+    from smpl_amd import capi
+    spheres = ["sphere l1 a 0.1 0 0 0.08 2", "sphere l2 b 0.1 0 0 0.06 2", "sphere l3 c 0 0 0.05 0.05 1", "sphere head h 0 0 0 0.1 1"]
+    text = formats.urdf_to_robot_text(ARM_URDF, "arm", ["l1", "l2", "l3"], ["j1", "j2", "j3"], "tool", spheres, [("l1", "l3")])
+    lines = text.splitlines()
+    assert lines[0] == "robot arm3" and lines[1] == "link base_link"
+    assert "link head" not in lines and not any(l.startswith("joint neck") for l in lines)   # off the group's sub-tree
+    assert any(l.startswith("joint j1 revolute base_link l1  0.0 0.0 0.3  0.0 0.0 0.5  0.0 0.0 1.0  -1.5 1.5") for l in lines)
+    assert any(l.startswith("joint j2 continuous l1 l2") for l in lines)
+    assert not any("sphere head" in l for l in lines) and "acm l1 l3" in lines
+    m = capi.Model(text)                                  # the host model compiler (no GPU needed)
+    assert (m.nvars, m.ntrees) == (3, 3)
+    # a non-planning movable joint on the kept chain is frozen at zero; a non-zero hold must be folded in by the caller
+    t2 = formats.urdf_to_robot_text(ARM_URDF, "arm", ["l1", "l2", "l3"], ["j1", "j3"], "tool", spheres)
+    assert any(l.startswith("joint j2 fixed l1 l2") for l in t2.splitlines())
+    with pytest.raises(ValueError):
+        formats.urdf_to_robot_text(ARM_URDF, "arm", ["l1", "l2", "l3"], ["j1", "j3"], "tool", spheres, held_at={"j2": 0.3})
+    with pytest.raises(ValueError):
+        formats.urdf_to_robot_text(ARM_URDF.replace('type="fixed"><parent link="head"', 'type="floating"><parent link="head"'),
+                                   "arm", ["l1"], ["j1"], "l1")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="the reference tree is only present in the build container")
+def test_group_links_from_the_reference_collision_yaml():
+    links = formats.group_links_from_collision_yaml(open(REF_YAML).read(), "right_gripper")
+    assert links == ["r_gripper_palm_link", "r_gripper_r_finger_link", "r_gripper_r_finger_tip_link", "r_gripper_l_finger_link",
+                     "r_gripper_l_finger_tip_link"]
+    assert formats.group_links_from_collision_yaml(open(REF_YAML).read(), "head") == ["head_pan_link", "head_tilt_link"]
+    with pytest.raises(ValueError):          # right_arm is a chain r_shoulder_pan_link -> r_wrist_roll_link: needs the URDF
+        formats.group_links_from_collision_yaml(open(REF_YAML).read(), "right_arm")
+
+
+def test_group_chains_resolve_through_the_urdf():
+    y = """
+robot_collision_model:
+  collision_groups:
+    - name: tip_group
+      links:
+        - name: tool
+    - name: arm
+      groups: [ tip_group ]
+      chains:
+        - base: l1
+          tip: l3
+"""
+    assert formats.group_links_from_collision_yaml(y, "arm", ARM_URDF) == ["tool", "l1", "l2", "l3"]
+    with pytest.raises(ValueError):
+        formats.group_links_from_collision_yaml(y.replace("base: l1", "base: head"), "arm", ARM_URDF)

@@ -81,3 +81,15 @@ def test_planner_on_a_gpu_built_grid_equals_the_oracle(small_cfg):
     fixed = capi.Grid(gr.origin, gr.dims, gr.res, gr.max_dist, gr.d2)
     with pytest.raises(capi.SmplxError):
         fixed.add_points(np.zeros((1, 3)))
+
+
+def test_reference_env_file_to_gpu_grid():
+    """Row N4 wired to the C-ABI: the reference's own smpl_test/env/tabletop.env (tests/golden) is parsed as
+    call_planner.cpp:158-207 parses it and its boxes become the voxel grid on the GPU; the field equals config 1's."""
+    import os
+    from smpl_amd import capi, formats
+    env = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tabletop.env")).read()
+    objs = formats.parse_env(env)
+    cfg = scenes.config1()
+    g = capi.Grid.from_boxes(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, [(c, s) for (_, c, s) in objs])
+    assert np.array_equal(g.d2(), cfg.grid.d2)
