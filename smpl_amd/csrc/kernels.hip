@@ -415,6 +415,10 @@ struct ChainState {
     bool pair_hit, recheck_all;
     unsigned long long pending;
     int npending;
+    // the tree whose root lookup is in flight (software pipelining, see const_chain): its link transform and the
+    // squared cell distance the lookup returns
+    double Tp[12];
+    int pd2;
 };
 
 template <int T_, int K, int KEND>
@@ -481,11 +485,15 @@ __device__ __forceinline__ void apply_joint_const(double q, double T[12])
     }
 }
 
-// check_tree with the root sphere as literals: in free space the root clears and nothing is read from LDS; a root
-// that does not clear hands over to the generic traversal at its children (larger child first, as check_tree does)
+// check_tree with the root sphere as literals, cut in two so that the root's grid lookup can be IN FLIGHT while the next
+// joint of the chain is computed (every tree used to cost one exposed L2/HBM round trip: the compare-and-branch sat
+// right behind its load).  issue_root computes the root position and starts the lookup; resolve_root, called after the
+// next joint's arithmetic, looks at the answer: in free space the root clears and nothing is read from LDS; a root that
+// does not clear hands over to the generic traversal at its children (larger child first, as check_tree does), with
+// the link transform kept in C.Tp.  The order of the lookups -- and so the tally, also of a colliding configuration --
+// is unchanged: tree k is resolved before tree k+1 is issued.
 template <int T_>
-__device__ __forceinline__ bool check_tree_const(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
-                                                 const double T[12], int& lookups, double root_p[3])
+__device__ __forceinline__ void issue_root(const SmplxGridDev& g, ChainState& C, int& lookups, double root_p[3])
 {
     constexpr double cx = CM_ROOT_CX[T_], cy = CM_ROOT_CY[T_], cz = CM_ROOT_CZ[T_];
 #pragma unroll
@@ -493,18 +501,29 @@ __device__ __forceinline__ bool check_tree_const(const ModelLds* __restrict__ M,
         // ((a*x + b*y) + c*z) + t with exactly-zero coefficients dropped (see apply_joint_const)
         double acc = 0.0;
         bool have = false;
-        if constexpr (cx != 0.0) { acc = T[4 * i + 0] * cx; have = true; }
-        if constexpr (cy != 0.0) { acc = have ? acc + T[4 * i + 1] * cy : T[4 * i + 1] * cy; have = true; }
-        if constexpr (cz != 0.0) { acc = have ? acc + T[4 * i + 2] * cz : T[4 * i + 2] * cz; have = true; }
-        root_p[i] = have ? acc + T[4 * i + 3] : T[4 * i + 3];
+        if constexpr (cx != 0.0) { acc = C.T[4 * i + 0] * cx; have = true; }
+        if constexpr (cy != 0.0) { acc = have ? acc + C.T[4 * i + 1] * cy : C.T[4 * i + 1] * cy; have = true; }
+        if constexpr (cz != 0.0) { acc = have ? acc + C.T[4 * i + 2] * cz : C.T[4 * i + 2] * cz; have = true; }
+        root_p[i] = have ? acc + C.T[4 * i + 3] : C.T[4 * i + 3];
     }
     ++lookups;
 #ifdef ABL_NO_LOOKUP
-    const int d2 = 60000 + (int)(root_p[0] * 0.0);
+    C.pd2 = 60000 + (int)(root_p[0] * 0.0);
 #else
-    const int d2 = grid_d2(g, root_p);
+    C.pd2 = grid_d2(g, root_p);
 #endif
-    if (!(d2 < CM_ROOT_THR[T_])) return true;
+    if constexpr (CM_ROOT_LEFT[T_] >= 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) C.Tp[i] = C.T[i];   // only a tree that can be descended into needs its transform later
+    }
+}
+
+template <int T_>
+__device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                             ChainState& C, int& lookups)
+{
+    (void)M;
+    if (!(C.pd2 < CM_ROOT_THR[T_])) return true;
     if constexpr (CM_ROOT_LEFT[T_] < 0) {
         return false;
     } else {
@@ -520,7 +539,7 @@ __device__ __forceinline__ bool check_tree_const(const ModelLds* __restrict__ M,
             const LDS_AS SmplxNode& nd = L.nodes[node];
             double c[3] = {nd.c[0], nd.c[1], nd.c[2]};
             double p[3];
-            xform(T, c, p);
+            xform(C.Tp, c, p);
             ++lookups;
 #ifdef ABL_NO_LOOKUP
             const int dd = 60000 + (int)(p[0] * 0.0);
@@ -541,7 +560,8 @@ __device__ __forceinline__ bool check_tree_const(const ModelLds* __restrict__ M,
     }
 }
 
-template <int J>
+// PT = the tree whose root lookup was issued at an earlier joint and has not been looked at yet (-1: none)
+template <int J, int PT>
 __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                             ChainState& C, int& lookups)
 {
@@ -559,22 +579,38 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
 #pragma unroll
             for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = C.T[i];
         }
+        // the lookup issued at the previous tree has had this joint's sincos and products to land behind
+        if constexpr (PT >= 0) {
+#ifndef ABL_NO_TREES
+            if (!resolve_root<PT>(M, L, g, C, lookups)) return false;
+#endif
+        }
         if constexpr (tree >= 0) {
             double rp[3];
 #ifdef ABL_NO_TREES
             rp[0] = C.T[3]; rp[1] = C.T[7]; rp[2] = C.T[11];
 #else
-            if (!check_tree_const<tree>(M, L, g, C.T, lookups, rp)) return false;
+            issue_root<tree>(g, C, lookups, rp);
 #endif
             constexpr int slot = CM_ROOT_SLOT[tree];
             if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
 #ifndef ABL_NO_PAIRS
             const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
 #endif
+            return const_chain<J + 1, tree>(M, L, g, C, lookups);
+        } else {
+            return const_chain<J + 1, -1>(M, L, g, C, lookups);
         }
-        return const_chain<J + 1>(M, L, g, C, lookups);
     } else {
-        return true;
+        if constexpr (PT >= 0) {
+#ifndef ABL_NO_TREES
+            return resolve_root<PT>(M, L, g, C, lookups);
+#else
+            return true;
+#endif
+        } else {
+            return true;
+        }
     }
 }
 
@@ -624,7 +660,8 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
 #pragma unroll
         for (int v = 0; v < CM_NV; ++v) C.q[v] = lds_d(L, L.q_base + v);
         C.pair_hit = false; C.recheck_all = false; C.pending = 0; C.npending = 0;
-        if (!const_chain<0>(M, L, g, C, lookups)) return false;
+        C.pd2 = 0;
+        if (!const_chain<0, -1>(M, L, g, C, lookups)) return false;
         pair_hit = C.pair_hit; recheck_all = C.recheck_all; pending = C.pending; npending = C.npending;
     }
     const int nj = 0;
