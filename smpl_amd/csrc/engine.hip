@@ -192,8 +192,11 @@ struct smplx_space {
     size_t lds_bytes = 0, blob_bytes = 0;
     // BFS
     int32_t* d_bfs = nullptr;
-    int32_t* d_queue[2] = {nullptr, nullptr};
+    int32_t* d_queue[2] = {nullptr, nullptr};   // brick lists of the two passes in flight (level mode: the two frontier queues)
     int32_t* d_counts = nullptr;
+    unsigned char* d_brick_flags = nullptr;     // brick mode: bricks whose halo changed in the current pass
+    bool bfs_level_mode = false;                // SMPLX_BFS=levels: the level-synchronous kernel of round 1 (A/B runs)
+    int bfs_bricks[3] = {0, 0, 0};
     int32_t* d_minus_one = nullptr;   // a device int holding -1 (k_expand: deferred pass without a counter)
     int64_t bfs_total = 0;
     int bfs_levels = 0;
@@ -351,6 +354,43 @@ int run_bfs(smplx_space* s, const double xyz[3])
         return SMPLX_OK;
     }
     const int origin = (c[2] + 1) * dx * dy + (c[1] + 1) * dx + (c[0] + 1);
+    if (!s->bfs_level_mode) {
+        // brick formulation (kernels.hip k_bfs_brick): passes over the flagged 8x8x8 bricks until none is flagged
+        const int nbx = s->bfs_bricks[0], nby = s->bfs_bricks[1], nbz = s->bfs_bricks[2];
+        const int nbricks = nbx * nby * nbz;
+        const int dz = g->n[2] + 2;
+        const int brick = ((c[2] / 8) * nby + (c[1] / 8)) * nbx + (c[0] / 8);
+        // two activation lists alternate, each cut into 16 sub-lists of nbricks entries with their own counters on separate
+        // lines: d_queue[0] holds the lists, d_counts the 2 x 16 counters
+        const int kShards = 16;
+        const size_t list_ints = (size_t)kShards * nbricks;
+        int32_t* lists = s->d_queue[0];
+        hipLaunchKernelGGL(k_bfs_brick_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, (size_t)origin, brick, lists, s->d_counts);
+        HIP_TRY(hipGetLastError());
+        const int grid = std::min(nbricks, 4096);
+        int pass = 0;
+        std::vector<int32_t> cnt(2 * kShards * 32);
+        const int chunk = 16;
+        while (true) {
+            for (int k = 0; k < chunk; ++k, ++pass) {
+                const int in = pass & 1, out = (pass + 1) & 1;
+                hipLaunchKernelGGL(k_bfs_brick, dim3(grid), dim3(512), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
+                                   lists + in * list_ints, s->d_counts + in * kShards * 32, s->d_counts + out * kShards * 32, nbricks,
+                                   s->d_brick_flags);
+                hipLaunchKernelGGL(k_bfs_compact, dim3(blocks_for(nbricks, 256)), dim3(256), 0, s->stream, s->d_brick_flags, nbricks,
+                                   lists + out * list_ints, s->d_counts + out * kShards * 32, nbricks);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(cnt.data(), s->d_counts, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            long pending = 0;
+            for (int k = 0; k < kShards; ++k) pending += cnt[(size_t)(pass & 1) * kShards * 32 + 32 * k];
+            if (pending == 0) break;
+            if (pass > 64 * (nbx + nby + nbz) + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
+        }
+        s->bfs_levels = pass;
+        return SMPLX_OK;
+    }
     hipLaunchKernelGGL(k_bfs_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, origin, s->d_queue[0], s->d_counts);
     HIP_TRY(hipGetLastError());
     int level = 0;
@@ -1124,11 +1164,19 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
     const int dx = grid->n[0] + 2, dy = grid->n[1] + 2, dz = grid->n[2] + 2;
     s->bfs_total = (int64_t)dx * dy * dz;
-    const size_t qn = (size_t)grid->n[0] * grid->n[1] * grid->n[2] + 64;
+    {
+        const char* env = getenv("SMPLX_BFS");
+        s->bfs_level_mode = env && std::strcmp(env, "levels") == 0;
+    }
+    for (int a = 0; a < 3; ++a) s->bfs_bricks[a] = (grid->n[a] + 7) / 8;
+    const size_t nbricks = (size_t)s->bfs_bricks[0] * s->bfs_bricks[1] * s->bfs_bricks[2];
+    const size_t qn = s->bfs_level_mode ? (size_t)grid->n[0] * grid->n[1] * grid->n[2] + 64 : 2 * 16 * nbricks + 64;
     if ((e = hipMalloc((void**)&s->d_bfs, sizeof(int32_t) * s->bfs_total)) != hipSuccess) return bail(e, "hipMalloc bfs");
+    if ((e = hipMalloc((void**)&s->d_brick_flags, nbricks + 64)) != hipSuccess) return bail(e, "hipMalloc bfs flags");
+    if ((e = hipMemset(s->d_brick_flags, 0, nbricks + 64)) != hipSuccess) return bail(e, "hipMemset bfs flags");
     if ((e = hipMalloc((void**)&s->d_queue[0], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
-    if ((e = hipMalloc((void**)&s->d_queue[1], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
-    if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * 4)) != hipSuccess) return bail(e, "hipMalloc bfs counts");
+    if ((e = hipMalloc((void**)&s->d_queue[1], sizeof(int32_t) * (s->bfs_level_mode ? qn : 64))) != hipSuccess) return bail(e, "hipMalloc bfs queue");
+    if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * (3 * 16 * 32 + 4))) != hipSuccess) return bail(e, "hipMalloc bfs counts");
     if ((e = hipMalloc((void**)&s->d_minus_one, sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc");
     { const int32_t m1 = -1; if ((e = hipMemcpy(s->d_minus_one, &m1, sizeof(m1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy"); }
     s->hs.bfs.dim_x = dx; s->hs.bfs.dim_y = dy; s->hs.bfs.dim_z = dz; s->hs.bfs.dim_xy = dx * dy;
@@ -1164,6 +1212,7 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_queue[0]) (void)hipFree(s->d_queue[0]);
     if (s->d_queue[1]) (void)hipFree(s->d_queue[1]);
     if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->d_brick_flags) (void)hipFree(s->d_brick_flags);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->d_table) (void)hipFree(s->d_table);
     if (s->stream) (void)hipStreamDestroy(s->stream);
