@@ -6,7 +6,7 @@ set -e
 OUT=gpurun_out/${1:-prof_round}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="bench.py --no-cpu --no-planner --multi-queries 0 --overlap-streams 1 --steps 50"
+ARGS="bench.py --no-cpu --no-planner --no-shard --no-k2 --overlap-streams 1 --scaling-batches= --steps 50"
 python3 $ARGS > "$OUT/bench_line.json" 2> "$OUT/bench.err"      # also warms the on-disk kernel cache
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python3 $ARGS > "$OUT/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT" -o fetch -- python3 $ARGS > "$OUT/fetch.log" 2>&1

@@ -68,7 +68,7 @@ def main(out, summary_path, stats_path):
                 for c, v in cs.items():
                     pmc.setdefault(k, {})[c + "_avg"] = round(sum(v) / len(v), 2)
     s = {"command": "tools/profile_round.sh (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in "
-                    "separate passes) over: python3 bench.py --no-cpu --no-planner --multi-queries 0 --overlap-streams 1 --steps 50",
+                    "separate passes) over: python3 bench.py --no-cpu --no-planner --no-shard --no-k2 --overlap-streams 1 --scaling-batches= --steps 50",
          "timed_step_kernels": {k: kernels[k] for k in STEP_KERNELS if k in kernels},
          "other_kernels": {k: v for k, v in kernels.items() if k not in STEP_KERNELS and k.startswith("k_")},
          "pmc_per_launch": pmc}
