@@ -1500,6 +1500,8 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const bool in_range = tid < (long long)B * nprims;
     int flags = SMPLX_F_INACTIVE, lookups = 0, performed = 0, evaluated = 0;
     int succ_id = -1, succ_h = 0;   // K5: id of the successor's coordinate in the device state table
+    int early_id = -1;
+    bool have_early = false;
     int ncfg = 0, slk = 0;   // configurations k_pipe_configs checked for this edge / lookups of the state's own check
     if (in_range) flags = out_flags[tid];
     // the model and the per-thread scratch are only needed by edges that overflowed the work list (normally none)
@@ -1546,6 +1548,8 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                 int* sc = out_coord + tid * nv;
                 MV_UNROLL
                 for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
+                // K5: the table lookup only needs the coordinates; issued here, its probe lands behind the planning-link FK
+                if (out_id) { early_id = table_lookup(Sq->table, sc, nv); have_early = true; }
                 double p[3];
                 planning_fk(M, sq, p);
                 bool is_goal;
@@ -1578,7 +1582,7 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         // K5: getHashEntry on the device copy of the state table (manip_lattice.cpp:1302-1316).  The id is only a
         // hint to the host (it skips its own lookup); ids are still ASSIGNED on the host, in commit order.
         if (out_id) {
-            if (flags & SMPLX_F_VALID) succ_id = table_lookup(Sq->table, out_coord + tid * nv, nv);
+            if (flags & SMPLX_F_VALID) succ_id = have_early ? early_id : table_lookup(Sq->table, out_coord + tid * nv, nv);
             out_id[tid] = succ_id;
         }
     }
