@@ -517,6 +517,29 @@ def main():
                           f"C++ -O2, same expansion bound), rate = expansions of all threads / longest thread's time inside "
                           f"plan(); BFS per goal ({sum(a['setup_s'] for a in acc) / max(nq_cpu, 1):.2f} s each on the CPU) excluded on both sides",
                 "all_sampled_queries_identical_to_gpu": bool(all(a["same"] for a in acc)), "host_cores": os.cpu_count()}
+        if single and Oracle is not None and spaces:
+            # row N3: postProcessPath (interpolate -> shortcut -> interpolate) of a found path -- the config-2 query itself
+            # does not reach its goal within the planner leg's bound under the fork's semantics, so the first shard query
+            # that solved is taken; upstream limit test so that the interpolation passes do their work
+            k = next((i for i, r in enumerate(res) if r["solved"]), None)
+            if k is not None:
+                sp = spaces[k]
+                P = sp.extract_path(res[k]["path"])
+                sp.post_process_path(P, True, True, True)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    got, st = sp.post_process_path(P, True, True, True)
+                tg = (time.perf_counter() - t0) / 5
+                o3 = Oracle(cfg)
+                t0 = time.perf_counter()
+                want, ec, sc_ = o3.post_process(P, True, True, True)
+                tc = time.perf_counter() - t0
+                out["post_process"] = {
+                    "query": int(first + k), "points_in": int(len(P)), "points_out": int(len(got)), "gpu_ms": round(tg * 1e3, 3),
+                    "cpu_ms": round(tc * 1e3, 3), "gpu_configs_checked": int(st["configs"]), "gpu_batches": int(st["edge_batches"]),
+                    "cpu_edge_checks": int(ec), "cpu_state_checks": int(sc_),
+                    "equal": bool(got.shape == want.shape and np.array_equal(got, want))}
+                del o3
         del spaces
 
     if rank == 0:
