@@ -97,13 +97,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU over RCCL.  Rehearsal on a box with fewer GPUs than ranks (SMPLX_BENCH_BACKEND=gloo): the ranks share
+    # the devices there are and the result records travel over gloo -- same control flow, not a measurement.
+    backend = os.environ.get("SMPLX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else None     # where the collectives' tensors live
 
     from smpl_amd import capi, scenes, shard
 
@@ -191,7 +200,7 @@ def main():
           "compact_bytes_per_launch": int(8 * tot_k5[0] + rb * tot_k5[1]), "dense_bytes_per_launch": int(B * M * (12 * N + 9))}
 
     # whole-job aggregate: units of all ranks / max-over-ranks time (one all-gather of three doubles per rank)
-    sc = shard.gather_scalars([float(evals), elapsed, float(valid)], dist, world, dev)
+    sc = shard.gather_scalars([float(evals), elapsed, float(valid)], dist, world, coll_dev)
     value, tmax, total_evals = shard.aggregate(sc[:, :2])
 
     # ---- roofline of the dominant kernel (k_pipe_configs: the collision check), this rank ---------------------------
@@ -463,11 +472,11 @@ def main():
         if dist is not None:
             dist.barrier()
         rec = shard.pack_records(first, res)
-        rows = shard.gather_query_records(rec, args.queries_per_gpu, dist, world, dev)    # the one collective of the path
+        rows = shard.gather_query_records(rec, args.queries_per_gpu, dist, world, coll_dev)    # the one collective of the path
         tot_exp = sum(r["expansions"] for r in res)
         tot_commit = sum(r["committed_succ_evals"] for r in res)
         tot_gpu = sum(r["gpu_succ_evals"] for r in res)
-        sc2 = shard.gather_scalars([tot_exp, wall, tot_commit, tot_gpu, sum(r["gpu_batches"] for r in res), t_set], dist, world, dev)
+        sc2 = shard.gather_scalars([tot_exp, wall, tot_commit, tot_gpu, sum(r["gpu_batches"] for r in res), t_set], dist, world, coll_dev)
         tmax2 = float(sc2[:, 1].max())
         summ = shard.summarize(rows)
         out["shard"] = {
