@@ -373,6 +373,12 @@ def main():
                                "sample": f"{r['passes']} pass(es) over the same {B}-state frontier batch "
                                          f"({r['evals']} evaluations, {r['seconds']:.1f} s), oracle/ C++ -O2, 1 thread, "
                                          f"logging/visualisation off, 4-byte cells; host has {os.cpu_count()} cores"}
+        # the same with the reference's own cell layout (48-byte array-of-structures cells over the padded grid,
+        # distance_map.h:110-127; 824 MB at 256^3): SURVEY 8(d) asks for both
+        o.use_aos_cells(True)
+        r48 = o.eval_batch_timed(Q, min(args.cpu_seconds, 5.0))
+        out["cpu_baseline"]["value_48_byte_cells"] = round(r48["evals"] / r48["seconds"], 1)
+        out["cpu_baseline"]["sample_48_byte_cells"] = f"{r48['passes']} pass(es), {r48['evals']} evaluations, {r48['seconds']:.1f} s"
         del o
 
     if single and not args.no_planner:

@@ -204,6 +204,13 @@ void orc_state_valid_batch_timed(void* h, const double* Q, int n, unsigned char*
     }
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
+// timing variant: look distances up in the reference's 48-byte array-of-structures cells (same values)
+void orc_use_aos_cells(void* h, int on)
+{
+    Ctx* c = (Ctx*)h;
+    if (on && c->grid.aos.empty()) c->grid.buildAosCells();
+    c->grid.use_aos = on != 0;
+}
 int orc_waypoint_count(void* h, const double* a, const double* b)
 {
     Ctx* c = (Ctx*)h;

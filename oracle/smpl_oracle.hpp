@@ -810,6 +810,27 @@ struct OccupancyGrid {
     std::vector<int> d2;             // interior cells only
     std::vector<double> sqrt_table;  // res * sqrt(i)
     mutable long lookups = 0;        // counts getSquaredDist calls (roofline accounting)
+    // The reference's own storage, for timing only ("dense grid with the reference's 48 B AoS cell and a
+    // compact 4 B variant, both stated"): DistanceMap keeps an array-of-structures of 48-byte cells over the PADDED grid
+    // (distance_map.h:110-127: x, y, z, dist, dist_new, counter, obs*, bucket, dir, pos), so a lookup touches one 48-byte
+    // record of an 824 MB array at 256^3 instead of 4 bytes of a 67 MB one.  Same values, same results.
+    struct RefCell { int x, y, z, dist, dist_new, counter; void* obs; int bucket, dir, pos; };
+    static_assert(sizeof(RefCell) == 48, "the reference's cell is 48 bytes");
+    std::vector<RefCell> aos;
+    bool use_aos = false;
+    void buildAosCells()
+    {
+        const size_t px = (size_t)n[0] + 2, py = (size_t)n[1] + 2, pz = (size_t)n[2] + 2;
+        aos.assign(px * py * pz, RefCell{0, 0, 0, 0, 0, 0, nullptr, -1, 0, 0});
+        for (int x = 0; x < n[0]; ++x)
+            for (int y = 0; y < n[1]; ++y)
+                for (int z = 0; z < n[2]; ++z) {
+                    RefCell& c = aos[((size_t)(x + 1) * py + (y + 1)) * pz + (z + 1)];
+                    c.x = x + 1; c.y = y + 1; c.z = z + 1;
+                    c.dist = c.dist_new = d2[((size_t)x * n[1] + y) * n[2] + z];
+                }
+        use_aos = true;
+    }
 
     void init(const double o[3], int nx, int ny, int nz, double resolution, double maxd, const int* cells)
     {
@@ -837,6 +858,7 @@ struct OccupancyGrid {
     double getCellDistance(int x, int y, int z) const
     {
         if (!isCellValid(x, y, z)) return 0.0;
+        if (use_aos) return sqrt_table[aos[((size_t)(x + 1) * ((size_t)n[1] + 2) + (y + 1)) * ((size_t)n[2] + 2) + (z + 1)].dist];
         return sqrt_table[d2[((size_t)x * n[1] + y) * n[2] + z]];
     }
     double getMetricDistance(double x, double y, double z) const

@@ -98,6 +98,11 @@ class Oracle:
         self.lib.orc_set_padding.argtypes = [C.c_void_p, C.c_double]
         self.lib.orc_set_padding(self.h, padding)
 
+    def use_aos_cells(self, on: bool = True):
+        """Timing variant: the reference's 48-byte AoS distance cells over the padded grid (same values)."""
+        self.lib.orc_use_aos_cells.argtypes = [C.c_void_p, C.c_int]
+        self.lib.orc_use_aos_cells(self.h, int(on))
+
     def set_order(self, chain: bool):
         self.lib.orc_set_traversal_order(self.h, 1 if chain else 0)
 

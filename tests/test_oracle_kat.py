@@ -286,3 +286,22 @@ def test_interpolate_path_fork_limit_test_and_upstream_behaviour(o, small_cfg):
     assert len(out) == 1 + sum(w - 1 for w in W) and checks == sum(W)
     assert np.array_equal(out[0], P[0]) and np.array_equal(out[W[0] - 1], P[1]) and np.array_equal(out[-1], P[2])
     assert np.all(np.diff(out[:, 0]) > 0)
+
+
+def test_reference_cell_layout_variant_gives_the_same_results(small_cfg):
+    """The oracle's timing variant with the reference's 48-byte array-of-structures cells over the padded grid
+    (distance_map.h:110-127) must be the same checker: flags, lookups and a bounded search identical."""
+    from oracle_binding import Oracle
+    from smpl_amd import scenes
+    a, b = Oracle(small_cfg), Oracle(small_cfg)
+    b.use_aos_cells(True)
+    for o in (a, b):
+        o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    for q in scenes.random_states(scenes.ARM7_LIMITS, 40, 21):
+        x, y = a.eval_state(q), b.eval_state(q)
+        assert np.array_equal(x["flags"], y["flags"]) and np.array_equal(x["lookups"], y["lookups"]) and np.array_equal(x["h"], y["h"])
+    for o in (a, b):
+        o.set_start(small_cfg.start)
+        o.search_params(5.0, 1.0, 1.0, True, True, 800, 800)
+    ra, rb = a.plan(), b.plan()
+    assert ra["cost"] == rb["cost"] and np.array_equal(ra["expansion_log"], rb["expansion_log"])
