@@ -215,6 +215,8 @@ struct smplx_space {
     bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
     bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
     int small_batch_max = 256;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
+    double small_latency_limit = 70e-6;   // SMPLX_SMALL_KERNEL=always lifts it, =never disables the single-launch kernel
+    bool small_zero_copy = true;          // SMPLX_SMALL_ZERO_COPY=0: the single-launch kernel with DMA copies instead of host-memory I/O
     DevBuf<unsigned long long> b_counters;
     PinBuf<double> p_q;
     DevBuf<unsigned char> b_out;   // packed outputs of a planner batch (OutView)
@@ -234,7 +236,25 @@ struct smplx_space {
     DevBuf<int32_t> b_ins;
     PinBuf<int32_t> p_ins;
     // speculative successor cache (per state id: evaluated but not yet committed successors)
-    struct Rec { int32_t cost; int32_t h; int32_t goal; int32_t known; };
+    struct Rec { int32_t cost; int32_t h; int32_t goal; int32_t known; int32_t prim; };
+    // Child speculation (the space's own batches: smplx_plan on one query, plain GetSuccs).  Under a greedy dive the state
+    // popped next is usually a child of the state just expanded -- a state that did not exist when the batch for its
+    // parent was issued, so nobody could have hinted it.  But its joint values are a pure function of the parent's
+    // (applyMotionPrimitive): the host computes the would-be children of the state that missed with the device's own
+    // arithmetic and lets them ride in the parent's batch as extra rows.  When the parent is committed and a child is
+    // CREATED from its record with bit-identical joint values, the child's evaluated successors are attached to the new
+    // state; if the coordinate already existed (another creator, possibly other joint values) they are dropped.
+    // Measured on config 2 (eps 5, 40 000 expansions): misses 7 693 -> 6 112, but every batch carries ~22 more rows and the
+    // search gets 12 % SLOWER (0.485 -> 0.555 s): this query is not dive-dominated -- most fresh children are created by
+    // expansions that were cache hits, which nothing speculates for.  So: off unless SMPLX_SPEC_CHILDREN=1.
+    bool spec_children = false;
+    int spec_parent = -1;                    // id whose children the last collected batch evaluated
+    int inflight_nspec = 0;                  // extra rows of the batch in flight
+    std::vector<int32_t> spec_prim;          // per extra row: primitive
+    std::vector<double> spec_q;              // per extra row: joint values (N each)
+    size_t spec_first_row = 0;               // collected: where the children's rows sit in the pinned output block (pv)
+    int spec_nrows = 0;
+    int64_t spec_attached = 0, spec_rows = 0;
     std::vector<int64_t> cache_off;     // per id: first record, -1 = not evaluated
     std::vector<int32_t> cache_cnt;
     std::vector<Rec> recs;
@@ -735,6 +755,7 @@ void reset_lattice(smplx_space* s)
     s->start_id = -1;
     s->pending_ins.clear();
     s->table_count = 0;
+    s->spec_parent = -1; s->inflight_nspec = 0; s->spec_nrows = 0;
     if (s->d_table) (void)hipMemsetAsync(s->d_table, 0, s->table_cap * (size_t)s->hs.table.stride * sizeof(int32_t), s->stream);
     // id 0 is reserved for the goal (manip_lattice.cpp:122); it has no coordinate and is never hashed
     s->coords.assign(s->N, 0);
@@ -743,6 +764,66 @@ void reset_lattice(smplx_space* s)
     s->cache_off.push_back(-1); s->cache_cnt.push_back(0);
     s->done_off.push_back(-1); s->done_cnt.push_back(0);
     s->eval_count.push_back(0);
+}
+
+// host mirrors of the device's mprim_active and applyMotionPrimitive (kernels.hip; manip_lattice_action_space.cpp:662-691,
+// 575-621) -- the same expressions in the same order, compiled with -ffp-contract=off like the kernels
+bool host_mprim_active(const SmplxActionsDev& A, double goal_dist, int type)
+{
+    if (type == SMPLX_MP_LONG) {
+        if (A.use_long_and_short) return true;
+        const bool near_goal = goal_dist <= A.thresh[SMPLX_MP_SHORT];
+        return !(A.enabled[SMPLX_MP_SHORT] && near_goal);
+    } else if (type == SMPLX_MP_SHORT) {
+        if (A.use_long_and_short) return A.enabled[type] != 0;
+        const bool near_goal = goal_dist <= A.thresh[type];
+        return A.enabled[type] && near_goal;
+    }
+    return A.enabled[type] && goal_dist <= A.thresh[type];
+}
+
+void host_apply_prim(const SmplxActionsDev& A, const double* parent, int pi, int nv, double* out)
+{
+    double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
+    if (A.xy_rotate_by_var3 && nv > 3) {
+        double sn, cs;
+        smplx_sincos(parent[3], &sn, &cs);
+        const double a0 = d0, a1 = d1;
+        d0 = cs * a0 + (-sn) * a1;
+        d1 = sn * a0 + cs * a1;
+    }
+    for (int v = 0; v < nv; ++v) {
+        const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
+        out[v] = d + parent[v];
+    }
+}
+
+// the would-be children of state `id` (child speculation, see smplx_space): primitive and joint values of each
+void speculate_children(smplx_space* s, int id)
+{
+    s->spec_prim.clear();
+    s->spec_q.clear();
+    if (!s->spec_children) return;
+    const SmplxActionsDev& A = s->actions.dev;
+    const int N = s->N;
+    // the metric goal distance the device will gate this state's primitives on, as far as the host can tell it from the
+    // state's heuristic (h = cost_per_cell * BFS distance; 32767 = wall or outside); a wrong guess only wastes rows
+    bool know_gd = false;
+    double gd = 0.0;
+    const int32_t h = s->h_of_id[id];
+    const int cpc = s->hs.bfs.cost_per_cell;
+    if (h == 32767) { gd = (double)0x7FFFFFFF * s->grid->res; know_gd = true; }
+    else if (cpc > 0 && h % cpc == 0) { gd = (double)(h / cpc) * s->grid->res; know_gd = true; }
+    const double* parent = &s->qs[(size_t)id * N];
+    for (int pi = 0; pi < s->M; ++pi) {
+        const int type = A.type[pi];
+        if (type != SMPLX_MP_LONG && type != SMPLX_MP_SHORT) continue;
+        if (know_gd && !host_mprim_active(A, gd, type)) continue;
+        s->spec_prim.push_back(pi);
+        const size_t o = s->spec_q.size();
+        s->spec_q.resize(o + N);
+        host_apply_prim(A, parent, pi, N, &s->spec_q[o]);
+    }
 }
 
 // evaluate the successors of `id` plus hinted frontier states in one frontier batch
@@ -810,8 +891,14 @@ int issue_batch(smplx_space* s, int id)
     const int N = s->N, M = s->M;
     const int cap = s->params.batch_states > 0 ? s->params.batch_states : 4096;
     select_batch(s, id, cap);
+    s->spec_parent = -1;   // the rows of the previous batch are about to be overwritten
     std::vector<int32_t>& batch = s->inflight;
-    const int B = (int)batch.size();
+    const int nreal = (int)batch.size();
+    speculate_children(s, id);
+    const int nspec = (int)s->spec_prim.size();
+    s->inflight_nspec = nspec;
+    s->spec_rows += nspec;
+    const int B = nreal + nspec;
     const size_t BM = (size_t)B * M;
     if (int e = reserve_expand(s, B)) return e;
     int e;
@@ -821,10 +908,14 @@ int issue_batch(smplx_space* s, int id)
     if ((e = s->p_out.reserve(out_bytes))) return e;
     s->dv = carve_out(s->b_out.p, BM, N);
     s->pv = carve_out(s->p_out.p, BM, N);
-    for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
+    auto pack_parents = [&]() {
+        for (int i = 0; i < nreal; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
+        if (nspec) std::memcpy(&s->p_q.p[(size_t)nreal * N], s->spec_q.data(), sizeof(double) * (size_t)nspec * N);
+    };
+    pack_parents();
     if (s->pipeline_left > 0 && B <= s->small_batch_max) --s->pipeline_left;   // sitting out on the pipeline path (see smplx_space)
-    s->inflight_zero_copy = takes_small_kernel(s, B);
-    s->inflight_small = s->inflight_zero_copy;
+    s->inflight_small = takes_small_kernel(s, B);
+    s->inflight_zero_copy = s->inflight_small && s->small_zero_copy;
     s->t_issue = std::chrono::steady_clock::now();
     // K5: the states committed since the last batch join the device table at the head of this batch's first kernel;
     // their (id, coordinate) triples ride in the parents' upload
@@ -836,7 +927,7 @@ int issue_batch(smplx_space* s, int id)
         if (!s->pending_ins.empty()) {
             if ((e = s->p_q.reserve((size_t)B * N + s->pending_ins.size() / 2 + 1))) return e;
             if ((e = s->b_q.reserve((size_t)B * N + s->pending_ins.size() / 2 + 1))) return e;
-            for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);   // the buffer may have moved
+            pack_parents();   // the buffer may have moved
             k5.n_items = (int)(s->pending_ins.size() / ((size_t)N + 2));
             item_doubles = stage_items(s->p_q, (size_t)B * N, s->pending_ins);
             s->pending_ins.clear();
@@ -874,7 +965,7 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         // issue-to-landing time of the single-launch path (the search thread has been polling since the issue)
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_issue).count();
         s->small_latency = s->small_seen == 0 ? dt : 0.8 * s->small_latency + 0.2 * dt;
-        if (++s->small_seen >= 16 && s->small_latency > 70e-6) { s->pipeline_left = 2000; s->small_seen = 0; }
+        if (++s->small_seen >= 16 && s->small_latency > s->small_latency_limit) { s->pipeline_left = 2000; s->small_seen = 0; }
     }
     if (src == s) { s->inflight_small = false; s->inflight_zero_copy = false; }
     for (int i = 0; i < B; ++i) {
@@ -891,6 +982,7 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
             r.h = pv.h[k];
             r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
             r.known = s->d_table ? pv.id[k] : -1;
+            r.prim = p;
             s->recs.push_back(r);
             s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
             s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
@@ -900,8 +992,59 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         s->eval_count[sid] = evals;
         s->gpu_evals += evals;
     }
+    // child speculation: the extra rows behind the real states hold the successors of the first state's would-be children.
+    // They are NOT ingested here: the parent is committed right after this (it is the state the search is waiting for),
+    // before another batch can overwrite the pinned output block, and only the rows of children that are really created
+    // get read (attach_speculated_child) -- the other rows cost the host nothing.
+    s->spec_parent = -1;
+    if (src == s && !view && s->inflight_nspec > 0 && B > 0) {
+        s->spec_parent = batch[0];
+        s->spec_first_row = first + (size_t)B;
+        s->spec_nrows = s->inflight_nspec;
+        for (int j = 0; j < s->inflight_nspec; ++j) {   // the evaluation tally only needs the flags
+            int evals = 0;
+            for (int p = 0; p < M; ++p) evals += (pv.flags[(s->spec_first_row + j) * M + p] & SMPLX_F_INACTIVE) ? 0 : 1;
+            s->gpu_evals += evals;
+        }
+    }
+    s->inflight_nspec = 0;
     s->inflight.clear();
     return SMPLX_OK;
+}
+
+// A state has just been CREATED from successor record `prim` of the state whose children were speculated: if the child's
+// joint values are, bit for bit, the ones the host computed for that row, the row's evaluated successors become the new
+// state's cache entry (what a GetSuccs miss on it would have fetched)
+void attach_speculated_child(smplx_space* s, int sid, int prim, const double* q)
+{
+    const int N = s->N, M = s->M;
+    const OutView& pv = s->pv;
+    for (int j = 0; j < s->spec_nrows; ++j) {
+        if (s->spec_prim[j] != prim) continue;
+        if (std::memcmp(&s->spec_q[(size_t)j * N], q, sizeof(double) * N) != 0) return;   // not the values that were evaluated
+        s->cache_off[sid] = (int64_t)s->recs.size();
+        int cnt = 0, evals = 0;
+        for (int p = 0; p < M; ++p) {
+            const size_t k = (s->spec_first_row + (size_t)j) * M + p;
+            const unsigned char f = pv.flags[k];
+            if (!(f & SMPLX_F_INACTIVE)) ++evals;
+            if (!(f & SMPLX_F_VALID)) continue;
+            smplx_space::Rec r;
+            r.cost = s->actions.dev.cost[p];
+            r.h = pv.h[k];
+            r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
+            r.known = s->d_table ? pv.id[k] : -1;
+            r.prim = p;
+            s->recs.push_back(r);
+            s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
+            s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
+            ++cnt;
+        }
+        s->cache_cnt[sid] = cnt;
+        s->eval_count[sid] = evals;
+        ++s->spec_attached;
+        return;
+    }
 }
 
 int run_batch(smplx_space* s, int id)
@@ -934,7 +1077,10 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
             // K5: the device table already named the state when the batch was evaluated (it only holds committed
             // states, so a hit is final); otherwise getOrCreateState on the host table
             int sid = r.known >= 0 ? r.known : s->table.find(c, s->coords);
-            if (sid < 0) sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
+            if (sid < 0) {
+                sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
+                if (s->spec_parent == id) attach_speculated_child(s, sid, r.prim, &s->qs[(size_t)sid * s->N]);
+            }
             s->done_succ.push_back(r.goal ? 0 : sid);
             s->done_cost.push_back(r.cost);
         }
@@ -1108,6 +1254,12 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->fused_mode = (params->reserved & 1) != 0;
     s->tiny_work_list = (params->reserved & 2) != 0;
     if (params->reserved & 4) s->small_batch_max = 0;
+    if (const char* e = getenv("SMPLX_SPEC_CHILDREN")) s->spec_children = e[0] != '0';
+    if (const char* e = getenv("SMPLX_SMALL_ZERO_COPY")) s->small_zero_copy = e[0] != '0';
+    if (const char* e = getenv("SMPLX_SMALL_KERNEL")) {
+        if (!std::strcmp(e, "always")) s->small_latency_limit = 1.0;
+        else if (!std::strcmp(e, "never")) s->small_batch_max = 0;
+    }
     if (const char* e = getenv("SMPLX_AUTO_SPECULATE")) s->auto_spec = std::max(0, atoi(e));
     if (const char* e = getenv("SMPLX_AUTO_SPECULATE_W")) s->auto_w = atof(e);
     s->N = s->model.dev.nvars;

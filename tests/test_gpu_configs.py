@@ -298,3 +298,28 @@ def test_device_table_on_and_off_give_the_same_search(small_cfg, monkeypatch):
     (a, na), (b, nb) = runs
     assert na == nb and na > (1 << 17)                      # more states than half the initial 2^18 slots: it grew
     assert a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"]) and np.array_equal(a["path"], b["path"])
+
+
+def test_child_speculation_switch_gives_the_same_search(small_cfg, monkeypatch):
+    """SMPLX_SPEC_CHILDREN=1: the would-be children of the state that missed ride in its batch (joint values computed on
+    the host with the device's arithmetic) and their evaluated successors are attached when the child is created with
+    bit-identical joint values.  Same search as without, and as the oracle's; and children do get attached."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); o.set_start(cfg.start)
+    o.search_params(5.0, 1.0, 1.0, True, True, 6000, 3000)
+    e = o.plan()
+    misses = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("SMPLX_SPEC_CHILDREN", env)
+        for no_small in (False, True):
+            s = capi.Space.from_config(cfg, batch_states=256, no_small_kernel=no_small)
+            s.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_start(cfg.start)
+            r = s.plan(5.0, 1.0, 1.0, True, True, 6000, 3000)
+            assert r["cost"] == e["cost"] and np.array_equal(r["expansion_log"], e["expansion_log"]) and np.array_equal(r["path"], e["path"])
+            assert r["committed_succ_evals"] == e["succ_evals"]
+            misses[(env, no_small)] = r["cache_misses"]
+    assert misses[("1", False)] < misses[("0", False)] and misses[("1", True)] < misses[("0", True)]
