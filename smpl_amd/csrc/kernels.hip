@@ -1642,15 +1642,20 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 // ---------------------------------------------------------------------------------------------
 // Small frontier batches (a search that misses on a handful of states): ONE launch instead of the four-kernel
 // pipeline, because at this size the cost is launch + dependency latency, not throughput.
-// One block per state, 8 lanes per primitive:
-//   lanes 0..6 of an edge  -> waypoints 1..7 of its collision check (configuration each)
-//   lane  7   of an edge   -> the successor's own bookkeeping: planning-link FK, heuristic, coordinates, goal test
-//   2 extra threads        -> the state itself (waypoint 0 of every edge) and its planning-link FK (goal distance)
-// Nothing waits for the gating: every primitive is evaluated and the goal-distance gate is applied when the lanes
-// of an edge combine (ballot over its 8 lanes), so all FK chains run concurrently.  Results are identical to the
-// pipeline.  An edge with more than 7 waypoints after the start wraps around its lanes.
+// One block per state; every WAVE has one role, so that no wave runs two long code paths one after the other
+// (round 1 put an edge's 7 waypoint lanes and its bookkeeping lane side by side in one wave: rocprofv3 counted
+// 7 200 VALU instructions per wave, four configurations' worth, and a sparse stream of such kernels runs at the idle
+// clock on this pool: 105-117 us per launch):
+//   config waves   lanes 0 .. 7 M - 1: lane (p, k) checks waypoints k+1, k+8, ... of edge p (an edge with more than
+//                  7 waypoints after the start wraps around its lanes); lane 7 M: the state itself (waypoint 0 of
+//                  every edge).  One configuration per lane, one code path per wave.
+//   last wave      lane p < M: the successor of primitive p -- joint values, limits, coordinates, planning-link FK,
+//                  goal test, heuristic, state-table lookup, and at the end the verdict; lane M: the state's metric goal
+//                  distance (the gate of the primitives).
+// Nothing waits for the gating: every primitive is evaluated and the goal-distance gate is applied when an edge's
+// results are combined.  Results are identical to the pipeline.
 // ---------------------------------------------------------------------------------------------
-#define SMPLX_SMALL_LANES 8
+#define SMPLX_SMALL_LANES 7   // waypoint lanes per edge
 
 extern "C" __global__ void __launch_bounds__(512)
 k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
@@ -1663,12 +1668,15 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               const int* __restrict__ ins_items, int n_ins)
 {
     // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
-    // as a few KB of PCIe stores than as four DMA copies); Q may itself be pinned host memory -- the parent's
+    // as a few KB of PCIe stores than as DMA copies); Q may itself be pinned host memory -- the parent's
     // joint values are staged into LDS once per block
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_goal_dist;
     __shared__ int s_state_bad, s_state_lookups;
     __shared__ double s_parent[SMPLX_MAX_VARS];
+    __shared__ double s_sq[SMPLX_MAX_PRIMS][SMPLX_MAX_VARS];   // successor joint values of every primitive
+    __shared__ int s_edge_bad[SMPLX_MAX_PRIMS], s_edge_lk[SMPLX_MAX_PRIMS];
+    (void)deferred_count;
     if (n_ins > 0 && table_insert_block(S, stab, ins_items, n_ins, B)) return;   // K5: see k_pipe_prep
     const int nth = blockDim.x;
     ModelLds Mv;
@@ -1681,15 +1689,87 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const SmplxBfsDev bfs = Sq->bfs;
     const int nprims = A.nprims, nv = MV_NVARS(M);
     const int t = threadIdx.x;
-    const int pi = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
-    const bool edge_thread = pi < nprims;
+    const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
+    const int book0 = (ncfg + 63) / 64 * 64;                  // first lane of the bookkeeping wave
     if (t < nv) s_parent[t] = Q[(refs ? refs[si] : (int64_t)si) * nv + t];
+    if (t < nprims) { s_edge_bad[t] = 0; s_edge_lk[t] = 0; }
     __syncthreads();
     const double* parent = s_parent;
-    const long long eid = (long long)si * nprims + pi;
 
-    // ---- the two state-level roles ----
-    if (t == nprims * SMPLX_SMALL_LANES) {            // the state itself: waypoint 0 of each edge
+    // ---- bookkeeping wave, first half: successor joint values of every primitive -> LDS and out_q ----
+    const int bp = t - book0;                                 // primitive of a bookkeeping lane
+    const bool book = bp >= 0 && bp < nprims;
+    int type = 0;
+    bool have_action = false;
+    if (book) {
+        type = A.type[bp];
+        if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) have_action = true;
+        else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) have_action = true;
+        if (have_action) {
+            double* sq = out_q + ((long long)si * nprims + bp) * nv;
+            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+                double d0 = A.delta[bp][0], d1 = nv > 1 ? A.delta[bp][1] : 0.0;
+                if (A.xy_rotate_by_var3 && nv > 3) {
+                    double sn, cs;
+                    smplx_sincos(parent[3], &sn, &cs);
+                    const double a0 = d0, a1 = d1;
+                    d0 = cs * a0 + (-sn) * a1;
+                    d1 = sn * a0 + cs * a1;
+                }
+                MV_UNROLL
+                for (int v = 0; v < nv; ++v) {
+                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[bp][v]);
+                    const double x = d + parent[v];
+                    s_sq[bp][v] = x;
+                    sq[v] = x;
+                }
+            } else {
+                MV_UNROLL
+                for (int v = 0; v < nv; ++v) { const double x = Sq->goal.angles[v]; s_sq[bp][v] = x; sq[v] = x; }
+            }
+        }
+    }
+    __syncthreads();   // every lane of every edge can read its successor's joint values from LDS
+
+    int h = 0, is_goal = 0, early_id = -1, W = 0;
+    bool limits_ok = false;
+    if (t < ncfg - 1) {
+        // ---- config lanes: one waypoint each ----
+        const int p = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
+        const int ty = A.type[p];
+        const bool act = ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
+        if (act) {
+            const double* sq = s_sq[p];
+            if (check_joint_limits(M, sq)) {
+                double motion = 0.0;
+                MV_UNROLL
+                for (int v = 0; v < nv; ++v) {
+                    const int vt = MV_TYPE(M, v);
+                    const double sv = parent[v], fv = sq[v];
+                    if (vt == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
+                    else if (vt == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
+                    else if (vt == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
+                }
+                int Wc = 0;
+                if (motion != 0.0) {
+                    Wc = (int)ceil(motion / 0.05) + 1;
+                    if (Wc < 2) Wc = 2;
+                }
+                int my_bad = 0, my_lk = 0;
+                // waypoints slot+1, slot+8, ...: an edge longer than 7 waypoints wraps around its lanes
+                for (int wp = slot + 1; wp < Wc && !my_bad; wp += SMPLX_SMALL_LANES) {
+                    EdgeRef e;
+                    e.start = parent; e.finish = sq;
+                    e.alpha = (double)wp * (1.0 / (double)(Wc - 1));
+                    const bool ok = config_valid(M, L, grid, e, my_lk);
+                    my_bad = ok ? 0 : 1;
+                }
+                if (my_bad) atomicOr(&s_edge_bad[p], 1);
+                if (my_lk) atomicAdd(&s_edge_lk[p], my_lk);
+            }
+        }
+    } else if (t == ncfg - 1) {
+        // ---- the state itself: waypoint 0 of each edge (same code path as the other lanes of its wave) ----
         EdgeRef e;
         e.start = parent; e.finish = parent; e.alpha = 0.0;
         int lk = 0;
@@ -1698,110 +1778,60 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         s_state_lookups = lk;
         state_bad_out[si] = ok ? 0 : 1;
         state_lookups_out[si] = lk;
-    } else if (t == nprims * SMPLX_SMALL_LANES + 1) {  // metric goal distance of the state (bfs_heuristic.cpp:129-138)
-        double p[3];
-        planning_fk(M, parent, p);
-        int c[3];
-        world_to_cell(grid, p, c);
-        const double gd = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
-        s_goal_dist = gd;
-        goal_dist_out[si] = gd;
-    }
-
-    // ---- per edge: successor joint values (lane 0 writes them), limits, waypoint count ----
-    int type = 0, W = 0;
-    bool have_action = false, limits_ok = false;
-    double* sq = out_q + eid * nv;
-    if (edge_thread) {
-        type = A.type[pi];
-        if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) have_action = true;
-        else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) have_action = true;
-        if (have_action && slot == 0) {
-            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
-                double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
-                if (A.xy_rotate_by_var3 && nv > 3) {
-                    double s, c;
-                    smplx_sincos(parent[3], &s, &c);
-                    const double a0 = d0, a1 = d1;
-                    d0 = c * a0 + (-s) * a1;
-                    d1 = s * a0 + c * a1;
-                }
-                MV_UNROLL
-                for (int v = 0; v < nv; ++v) {
-                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
-                    sq[v] = d + parent[v];
-                }
-            } else {
-                MV_UNROLL
-                for (int v = 0; v < nv; ++v) sq[v] = Sq->goal.angles[v];
-            }
-        }
-    }
-    __syncthreads();   // successor joint values are in memory for every lane of their edge
-    if (edge_thread && have_action) {
+    } else if (book && have_action) {
+        // ---- bookkeeping lane of primitive bp: limits, waypoint count, coordinates, planning-link FK, goal test, heuristic ----
+        const double* sq = s_sq[bp];
         limits_ok = check_joint_limits(M, sq);
         if (limits_ok) {
             double motion = 0.0;
             MV_UNROLL
             for (int v = 0; v < nv; ++v) {
-                const int ty = MV_TYPE(M, v);
+                const int vt = MV_TYPE(M, v);
                 const double sv = parent[v], fv = sq[v];
-                if (ty == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
-                else if (ty == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
-                else if (ty == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
+                if (vt == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
+                else if (vt == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
+                else if (vt == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
             }
             if (motion != 0.0) {
                 W = (int)ceil(motion / 0.05) + 1;
                 if (W < 2) W = 2;
             }
-        }
-    }
-
-    // ---- lanes 0..6: one waypoint each; lane 7: the successor's bookkeeping ----
-    int my_bad = 0, my_lk = 0;
-    int h = 0, is_goal = 0, early_id = -1;
-    if (edge_thread && have_action && limits_ok) {
-        if (slot < SMPLX_SMALL_LANES - 1) {
-            // waypoints slot+1, slot+8, ...: an edge longer than 7 waypoints wraps around its lanes
-            for (int wp = slot + 1; wp < W && !my_bad; wp += SMPLX_SMALL_LANES - 1) {
-                EdgeRef e;
-                e.start = parent; e.finish = sq;
-                e.alpha = (double)wp * (1.0 / (double)(W - 1));
-                const bool ok = config_valid(M, L, grid, e, my_lk);
-                my_bad = ok ? 0 : 1;
-            }
-        } else {
-            int* sc = out_coord + eid * nv;
+            int* sc = out_coord + ((long long)si * nprims + bp) * nv;
             MV_UNROLL
             for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
-            double p[3];
-            planning_fk(M, sq, p);
+            // K5: the table lookup only needs the coordinates: issued here, it lands behind the planning-link FK
+            if (out_id) early_id = table_lookup(Sq->table, sc, nv);
+            double pw[3];
+            planning_fk(M, sq, pw);
             if (Sq->goal.type == SMPLX_GOAL_JOINT) {
                 is_goal = 1;
                 MV_UNROLL
                 for (int v = 0; v < nv; ++v)
                     if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = 0;
             } else {
-                is_goal = fabs(p[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(p[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
-                          fabs(p[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
+                is_goal = fabs(pw[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(pw[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
+                          fabs(pw[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
             }
             int c[3];
-            world_to_cell(grid, p, c);
+            world_to_cell(grid, pw, c);
             h = bfs_cost_to_goal(bfs, c);
-            // K5: the table lookup only needs the coordinates: issued here, it lands while the lanes of the edge and the
-            // state's own check are still working
-            if (out_id) early_id = table_lookup(Sq->table, sc, nv);
         }
+    } else if (bp == nprims) {
+        // ---- metric goal distance of the state (bfs_heuristic.cpp:129-138): the gate of its primitives ----
+        double pw[3];
+        planning_fk(M, parent, pw);
+        int c[3];
+        world_to_cell(grid, pw, c);
+        const double gd = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
+        s_goal_dist = gd;
+        goal_dist_out[si] = gd;
     }
-    __syncthreads();   // the state's own check and the goal distance have landed in LDS
+    __syncthreads();   // the waypoint verdicts, the state's own check and the goal distance have landed in LDS
 
-    // ---- combine the 8 lanes of each edge (they sit in one wave) ----
-    const unsigned long long bad_mask = __ballot(my_bad);
-    int lk = my_lk;
-    lk += __shfl_xor(lk, 1); lk += __shfl_xor(lk, 2); lk += __shfl_xor(lk, 4);
-    if (edge_thread && slot == SMPLX_SMALL_LANES - 1) {
-        const int lane = t & 63;
-        const bool edge_bad = ((bad_mask >> (lane & ~7)) & 0xFFull) != 0;
+    // ---- bookkeeping lanes: the verdict of their edge ----
+    if (book) {
+        const long long eid = (long long)si * nprims + bp;
+        const int* sc = out_coord + eid * nv;
         int flags;
         int lookups = 0, cost = 0, hh = 0;
         if (!have_action || !mprim_active(A, s_goal_dist, type)) {
@@ -1809,14 +1839,14 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         } else if (!limits_ok) {
             flags = SMPLX_F_LIMITS;
         } else {
-            lookups = lk + (W > 0 ? s_state_lookups : 0);
-            const bool ok = (W == 0) || (s_state_bad == 0 && !edge_bad);
+            lookups = s_edge_lk[bp] + (W > 0 ? s_state_lookups : 0);
+            const bool ok = (W == 0) || (s_state_bad == 0 && s_edge_bad[bp] == 0);
             if (!ok) {
                 flags = SMPLX_F_COLLISION;
             } else {
                 flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
                 hh = h;
-                cost = A.cost[pi];
+                cost = A.cost[bp];
             }
         }
         out_flags[eid] = (unsigned char)flags;
@@ -1833,9 +1863,8 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             if (host_id) host_id[eid] = sid;
             if (flags & SMPLX_F_VALID) {
                 host_h[eid] = hh;
-                const int* sc = out_coord + eid * nv;
                 MV_UNROLL
-                for (int v = 0; v < nv; ++v) { host_coord[eid * nv + v] = sc[v]; host_q[eid * nv + v] = sq[v]; }
+                for (int v = 0; v < nv; ++v) { host_coord[eid * nv + v] = sc[v]; host_q[eid * nv + v] = s_sq[bp][v]; }
             }
         }
     }
