@@ -176,7 +176,10 @@ int smplx_bfs_levels(const smplx_space* s);
 /* successor evaluation for B arbitrary parent states: the loop body of GetSuccs
  * (manip_lattice.cpp:254-305) for every (state, primitive), dense outputs indexed [state][prim]:
  * flags (SMPLX_F_* of device_types.h: 1 valid, 2 goal, 0x10 inactive, 0x20 limits, 0x40 collision),
- * coord[nvars], q[nvars], h, cost, lookups.  Any output may be NULL. */
+ * coord[nvars], q[nvars], h, cost, lookups.  Any output may be NULL.
+ * Defined entries: flags everywhere; coord, h and cost where flags has the valid bit (h and cost are 0 elsewhere); q on every
+ * edge that is not inactive; lookups on every edge not in collision (a colliding edge's tally stops at its first colliding
+ * waypoint lane).  Other entries hold whatever the kernel that served the batch left there. */
 int smplx_expand_batch(smplx_space* s, const double* q, int B, uint8_t* flags, int32_t* coord, double* succ_q,
                        int32_t* h, int32_t* cost, int32_t* lookups);
 /* same, everything resident in HBM; launches on `stream` and returns without synchronising.

@@ -1643,17 +1643,15 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 // Small frontier batches (a search that misses on a handful of states): ONE launch instead of the four-kernel
 // pipeline, because at this size the cost is launch + dependency latency, not throughput.
 // One block per state; every WAVE has one role, so that no wave runs two long code paths one after the other
-// (round 1 put an edge's 7 waypoint lanes and its bookkeeping lane side by side in one wave: rocprofv3 counted
-// 7 200 VALU instructions per wave, four configurations' worth, and a sparse stream of such kernels runs at the idle
-// clock on this pool: 105-117 us per launch):
+// (round 1 put an edge's 7 waypoint lanes and its bookkeeping lane side by side in one wave):
 //   config waves   lanes 0 .. 7 M - 1: lane (p, k) checks waypoints k+1, k+8, ... of edge p (an edge with more than
 //                  7 waypoints after the start wraps around its lanes); lane 7 M: the state itself (waypoint 0 of
 //                  every edge).  One configuration per lane, one code path per wave.
 //   last wave      lane p < M: the successor of primitive p -- joint values, limits, coordinates, planning-link FK,
 //                  goal test, heuristic, state-table lookup, and at the end the verdict; lane M: the state's metric goal
 //                  distance (the gate of the primitives).
-// Nothing waits for the gating: every primitive is evaluated and the goal-distance gate is applied when an edge's
-// results are combined.  Results are identical to the pipeline.
+// The goal distance is computed first (one lane, while the successor joint values are formed): only the primitives it
+// activates have their waypoints checked.  Results are identical to the pipeline.
 // ---------------------------------------------------------------------------------------------
 #define SMPLX_SMALL_LANES 7   // waypoint lanes per edge
 
@@ -1729,7 +1727,20 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             }
         }
     }
-    __syncthreads();   // every lane of every edge can read its successor's joint values from LDS
+    if (bp == nprims) {
+        // ---- metric goal distance of the state (bfs_heuristic.cpp:129-138): the gate of its primitives.  It has to be
+        // known BEFORE the waypoint lanes start: an ungated snap-to-goal primitive is an edge of a hundred waypoints,
+        // 15 configurations in sequence on each of its 7 lanes (measured: 104 us per launch, 25 000 VALU instructions
+        // per state where the pipeline spends 2 500) ----
+        double pw[3];
+        planning_fk(M, parent, pw);
+        int c[3];
+        world_to_cell(grid, pw, c);
+        const double gd = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
+        s_goal_dist = gd;
+        goal_dist_out[si] = gd;
+    }
+    __syncthreads();   // every lane of every edge can read its successor's joint values and the gate from LDS
 
     int h = 0, is_goal = 0, early_id = -1, W = 0;
     bool limits_ok = false;
@@ -1738,7 +1749,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         const int p = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
         const int ty = A.type[p];
         const bool act = ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
-        if (act) {
+        if (act && mprim_active(A, s_goal_dist, ty)) {
             const double* sq = s_sq[p];
             if (check_joint_limits(M, sq)) {
                 double motion = 0.0;
@@ -1816,17 +1827,8 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             world_to_cell(grid, pw, c);
             h = bfs_cost_to_goal(bfs, c);
         }
-    } else if (bp == nprims) {
-        // ---- metric goal distance of the state (bfs_heuristic.cpp:129-138): the gate of its primitives ----
-        double pw[3];
-        planning_fk(M, parent, pw);
-        int c[3];
-        world_to_cell(grid, pw, c);
-        const double gd = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
-        s_goal_dist = gd;
-        goal_dist_out[si] = gd;
     }
-    __syncthreads();   // the waypoint verdicts, the state's own check and the goal distance have landed in LDS
+    __syncthreads();   // the waypoint verdicts and the state's own check have landed in LDS
 
     // ---- bookkeeping lanes: the verdict of their edge ----
     if (book) {

@@ -87,8 +87,14 @@ def test_config2_256cube_bfs_frontier_batch_and_bounded_search(cfg2):
     got = s.expand_batch(Q)
     rows = np.r_[0:64, 2000:2064, 4032:4096]
     sub = _compare_batch(o, s, Q[rows])
-    for k in ("flags", "coord", "q", "h", "cost"):
-        assert np.array_equal(sub[k], got[k][rows])
+    # the two calls may take different kernels (single launch / pipeline): equal wherever an output is defined
+    # (include/smpl_amd.h: coord, h, cost on valid edges; q on every edge that is not inactive)
+    assert np.array_equal(sub["flags"], got["flags"][rows])
+    v = (sub["flags"] & 1) != 0
+    act = (sub["flags"] & 0x10) == 0
+    for k in ("coord", "h", "cost"):
+        assert np.array_equal(sub[k][v], got[k][rows][v])
+    assert np.array_equal(sub["q"][act], got["q"][rows][act])
     again = np.concatenate([s.expand_batch(Q[i:i + 512])["flags"] for i in range(0, 4096, 512)])
     assert np.array_equal(again, got["flags"])
 
