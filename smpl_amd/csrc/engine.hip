@@ -155,10 +155,11 @@ struct OutView {
     int32_t* h = nullptr;
     int32_t* id = nullptr;      // K5: state id of the successor's coordinate in the device table, -1 = not there
     unsigned char* flags = nullptr;
+    int32_t* sel = nullptr;     // N2: per row, the edge a rollout row continued from (SmplxRollDev::out_sel)
     size_t bytes = 0;
 };
 
-inline OutView carve_out(unsigned char* base, size_t BM, int N)
+inline OutView carve_out(unsigned char* base, size_t BM, int N, size_t rows = 0)
 {
     OutView v;
     size_t o = 0;
@@ -166,6 +167,7 @@ inline OutView carve_out(unsigned char* base, size_t BM, int N)
     v.coord = (int32_t*)(base + o); o += BM * N * sizeof(int32_t);
     v.h = (int32_t*)(base + o); o += BM * sizeof(int32_t);
     v.id = (int32_t*)(base + o); o += BM * sizeof(int32_t);
+    v.sel = (int32_t*)(base + o); o += (rows + 3) / 4 * 4 * sizeof(int32_t);
     v.flags = base + o; o += BM;
     v.bytes = (o + 15) / 16 * 16;
     return v;
@@ -248,6 +250,26 @@ struct smplx_space {
     // search gets 12 % SLOWER (0.485 -> 0.555 s): this query is not dive-dominated -- most fresh children are created by
     // expansions that were cache hits, which nothing speculates for.  So: off unless SMPLX_SPEC_CHILDREN=1.
     bool spec_children = false;
+    // N2 -- expansion continued on the device (rollout rows).  Most misses are on states that were created a moment ago
+    // by an expansion served from the cache: nobody could have hinted them, they did not exist.  So every batch also
+    // evaluates, for its first roll_rows states, the roll_beam best successors (cost + w*h) and, below each, a chain of
+    // best successors roll_depth deep -- rows whose parents are read from the batch's own outputs in HBM (k_small_batch
+    // in rollout mode, one launch per level).  Their records wait in the cache as phantom nodes hanging off the state
+    // they descend from; when that state is committed and the successor is CREATED from the very record the device
+    // continued from (same joint values by construction), the node becomes the new state's cache entry and its own
+    // children move along.  A wrong guess costs GPU rows and host ingest, never results.
+    int roll_depth = 0, roll_beam = 1, roll_rows = 64, roll_w = 5;
+    bool roll_w_fixed = false;               // SMPLX_ROLLOUT_W given: the engine's own search does not set w = eps
+    struct Ph { int64_t rec_off; int32_t cnt, evals, prim, next, child; };
+    std::vector<Ph> ph;
+    std::vector<int32_t> ph_head;            // per id: first phantom child, -1 = none
+    struct RollPlan { int B = 0, R = 0, K = 0, D = 0; int extra() const { return R * K * D; } };
+    RollPlan inflight_roll;
+    int64_t roll_rows_total = 0, roll_attached = 0;
+    // SMPLX_DEBUG_TIMING: how old (in expansions) the states are that the search misses on
+    bool dbg_birth_on = false;
+    std::vector<int32_t> dbg_birth;
+    int64_t dbg_age_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int spec_parent = -1;                    // id whose children the last collected batch evaluated
     int inflight_nspec = 0;                  // extra rows of the batch in flight
     std::vector<int32_t> spec_prim;          // per extra row: primitive
@@ -593,6 +615,7 @@ struct ZeroCopy {
     double* sq = nullptr;
     int32_t* h = nullptr;
     int32_t* id = nullptr;
+    int32_t* sel = nullptr;
 };
 
 bool small_kernel_fits(const smplx_space* s, int B)
@@ -606,9 +629,12 @@ bool small_kernel_fits(const smplx_space* s, int B)
 int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
                   hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr,
-                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false, const K5Out* k5 = nullptr)
+                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false, const K5Out* k5 = nullptr,
+                  const smplx_space::RollPlan* roll = nullptr, int32_t* d_sel = nullptr)
 {
-    ExpandWork k = carve_work(d_work, B, s->M);
+    // a batch with rollout rows: the caller sized every buffer for B + roll->extra() rows
+    const int Btot = B + (roll ? roll->extra() : 0);
+    ExpandWork k = carve_work(d_work, Btot, s->M);
     int32_t* d_id = k5 ? k5->d_id : nullptr;
     SmplxCompactDev cmp;
     std::memset(&cmp, 0, sizeof(cmp));
@@ -624,6 +650,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int64_t* norefs = nullptr;
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    SmplxRollDev noroll;
+    std::memset(&noroll, 0, sizeof(noroll));
     if (!force_pipeline && !s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
         !s->tiny_work_list && s->pipeline_left == 0) {
         ++s->small_launches;
@@ -634,7 +662,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
                            zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
                            zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
-                           zero_copy ? zero_copy->id : (int32_t*)nullptr, ins_items, n_ins);
+                           zero_copy ? zero_copy->id : (int32_t*)nullptr, ins_items, n_ins, noroll);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (d_id) HIP_TRY(hipMemsetAsync(d_id, 0xFF, sizeof(int32_t) * (size_t)B * s->M, stream));   // fused mode: no table lookups
@@ -669,8 +697,43 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            d_cost, d_lookups, d_counters, k.goal_dist, stab, state_q, d_id, cmp);
         if (ev) (void)hipEventRecord(ev[2], stream);
     }
+    if (roll && roll->extra() > 0 && d_sel) {
+        // N2: one launch per level; level l reads its parents from the rows of level l-1 (level 1: from the real rows)
+        const int RK = roll->R * roll->K;
+        for (int l = 1; l <= roll->D; ++l) {
+            SmplxRollDev rd;
+            rd.on = 1;
+            rd.row0 = B + (l - 1) * RK;
+            rd.base = l == 1 ? 0 : B + (l - 2) * RK;
+            rd.mod = l == 1 ? roll->R : 0;
+            rd.rank_div = l == 1 ? roll->R : 0;
+            rd.w = s->roll_w;
+            rd.out_sel = d_sel;
+            rd.host_sel = zero_copy ? zero_copy->sel : (int32_t*)nullptr;
+            KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(RK), dim3(small_block), small_lds, stream, s->d_space, (const double*)d_sq, norefs, Btot,
+                    k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
+                    zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
+                    zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
+                    zero_copy ? zero_copy->id : (int32_t*)nullptr, (const int32_t*)nullptr, 0, rd);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return SMPLX_OK;
+}
+
+// N2: how many rollout rows a batch of B states gets (none when the single-launch kernel does not fit this robot)
+smplx_space::RollPlan plan_roll(const smplx_space* s, int B)
+{
+    smplx_space::RollPlan rp;
+    rp.B = B;
+    if (s->roll_depth <= 0 || s->roll_beam <= 0 || s->fused_mode || s->tiny_work_list || !s->prof_events.empty()) return rp;
+    const int small_block = smplx_small_block(s->M);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    if (small_block > 512 || small_lds > 150 * 1024) return rp;
+    rp.R = std::min(B, s->roll_rows);
+    rp.K = s->roll_beam;
+    rp.D = s->roll_depth;
+    return rp;
 }
 
 int reserve_expand(smplx_space* s, int B)
@@ -700,6 +763,8 @@ int new_state(smplx_space* s, const int32_t* coord, const double* q, int32_t h)
     s->done_off.push_back(-1);
     s->done_cnt.push_back(0);
     s->eval_count.push_back(0);
+    s->ph_head.push_back(-1);
+    if (s->dbg_birth_on) s->dbg_birth.push_back((int32_t)s->expansion_log.size());
     s->table.insert(id, s->coords);
     if (s->plain_mode) s->g_est.push_back(1000000000u);
     if (s->d_table) {
@@ -764,6 +829,10 @@ void reset_lattice(smplx_space* s)
     s->cache_off.push_back(-1); s->cache_cnt.push_back(0);
     s->done_off.push_back(-1); s->done_cnt.push_back(0);
     s->eval_count.push_back(0);
+    s->ph.clear();
+    s->ph_head.assign(1, -1);
+    s->dbg_birth.assign(1, 0);
+    s->inflight_roll = smplx_space::RollPlan();
 }
 
 // host mirrors of the device's mprim_active and applyMotionPrimitive (kernels.hip; manip_lattice_action_space.cpp:662-691,
@@ -894,20 +963,25 @@ int issue_batch(smplx_space* s, int id)
     s->spec_parent = -1;   // the rows of the previous batch are about to be overwritten
     std::vector<int32_t>& batch = s->inflight;
     const int nreal = (int)batch.size();
-    speculate_children(s, id);
+    const smplx_space::RollPlan rp = plan_roll(s, nreal);   // N2 rollout rows (they replace host-side child speculation)
+    if (rp.extra() > 0) { s->spec_prim.clear(); s->spec_q.clear(); }
+    else speculate_children(s, id);
     const int nspec = (int)s->spec_prim.size();
     s->inflight_nspec = nspec;
     s->spec_rows += nspec;
+    s->inflight_roll = rp;
+    s->roll_rows_total += rp.extra();
     const int B = nreal + nspec;
-    const size_t BM = (size_t)B * M;
-    if (int e = reserve_expand(s, B)) return e;
+    const int Btot = B + rp.extra();
+    const size_t BM = (size_t)Btot * M;
+    if (int e = reserve_expand(s, Btot)) return e;
     int e;
     if ((e = s->p_q.reserve((size_t)B * N))) return e;
-    const size_t out_bytes = carve_out(nullptr, BM, N).bytes;
+    const size_t out_bytes = carve_out(nullptr, BM, N, Btot).bytes;
     if ((e = s->b_out.reserve(out_bytes))) return e;
     if ((e = s->p_out.reserve(out_bytes))) return e;
-    s->dv = carve_out(s->b_out.p, BM, N);
-    s->pv = carve_out(s->p_out.p, BM, N);
+    s->dv = carve_out(s->b_out.p, BM, N, Btot);
+    s->pv = carve_out(s->p_out.p, BM, N, Btot);
     auto pack_parents = [&]() {
         for (int i = 0; i < nreal; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
         if (nspec) std::memcpy(&s->p_q.p[(size_t)nreal * N], s->spec_q.data(), sizeof(double) * (size_t)nspec * N);
@@ -937,8 +1011,9 @@ int issue_batch(smplx_space* s, int id)
         k5.items = (const int32_t*)(s->p_q.p + (size_t)B * N);
         ZeroCopy zc;
         zc.q = s->p_q.p; zc.flags = s->pv.flags; zc.coord = s->pv.coord; zc.sq = s->pv.sq; zc.h = s->pv.h; zc.id = s->pv.id;
+        zc.sel = s->pv.sel;
         if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc, false, &k5))) return e;
+                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc, false, &k5, &rp, s->dv.sel))) return e;
         HIP_TRY(hipEventRecord(s->batch_done, s->stream));
         ++s->gpu_batches;
         return SMPLX_OK;
@@ -946,52 +1021,98 @@ int issue_batch(smplx_space* s, int id)
     HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * ((size_t)B * N + item_doubles), hipMemcpyHostToDevice, s->stream));
     k5.items = (const int32_t*)(s->b_q.p + (size_t)B * N);
     if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                           s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, nullptr, false, &k5))) return e;
+                           s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, nullptr, false, &k5, &rp, s->dv.sel))) return e;
     HIP_TRY(hipMemcpyAsync(s->p_out.p, s->b_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));   // one copy for all five outputs
     HIP_TRY(hipEventRecord(s->batch_done, s->stream));
     ++s->gpu_batches;
     return SMPLX_OK;
 }
 
+// one dense output row -> cached successor records (appended to recs); returns the record count
+int ingest_row(smplx_space* s, const OutView& pv, size_t row, int* evals_out)
+{
+    const int N = s->N, M = s->M;
+    int cnt = 0, evals = 0;
+    for (int p = 0; p < M; ++p) {
+        const size_t k = row * M + p;
+        const unsigned char f = pv.flags[k];
+        if (!(f & SMPLX_F_INACTIVE)) ++evals;
+        if (!(f & SMPLX_F_VALID)) continue;
+        smplx_space::Rec r;
+        r.cost = s->actions.dev.cost[p];
+        r.h = pv.h[k];
+        r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
+        r.known = s->d_table ? pv.id[k] : -1;
+        r.prim = p;
+        s->recs.push_back(r);
+        s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
+        s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
+        ++cnt;
+    }
+    *evals_out = evals;
+    return cnt;
+}
+
+// N2: the rollout chains below real row `c` of a batch (row index within the whole batch) become phantom nodes of `sid`
+void ingest_rollouts(smplx_space* s, const OutView& pv, const smplx_space::RollPlan& rp, int c, int sid)
+{
+    if (c >= rp.R) return;
+    const int M = s->M, RK = rp.R * rp.K;
+    for (int kb = 0; kb < rp.K; ++kb) {
+        const int chain = kb * rp.R + c;
+        int parent_node = -1;   // -1: the real state
+        size_t want_src = (size_t)c;
+        for (int l = 1; l <= rp.D; ++l) {
+            const size_t row = (size_t)rp.B + (size_t)(l - 1) * RK + chain;
+            const int32_t sel = pv.sel[row];
+            if (sel < 0 || (size_t)(sel / M) != want_src) break;   // nothing to continue from
+            smplx_space::Ph node;
+            node.rec_off = (int64_t)s->recs.size();
+            node.cnt = ingest_row(s, pv, row, &node.evals);
+            node.prim = sel % M;
+            node.child = -1;
+            s->gpu_evals += node.evals;
+            const int idx = (int)s->ph.size();
+            if (parent_node < 0) { node.next = s->ph_head[sid]; s->ph_head[sid] = idx; }
+            else { node.next = s->ph[parent_node].child; s->ph[parent_node].child = idx; }
+            s->ph.push_back(node);
+            parent_node = idx;
+            want_src = row;
+        }
+    }
+}
+
 // the batch in flight has completed: turn its dense outputs into cached successor records
-int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0, const OutView* view = nullptr)
+int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0, const OutView* view = nullptr,
+                  const smplx_space::RollPlan* roll = nullptr)
 {
     if (!src) src = s;   // a cross-query batch lands in the leading space's buffers (or in `view`), at row `first`
     const OutView& pv = view ? *view : src->pv;
-    const int N = s->N, M = s->M;
+    const int M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
     if (src == s && s->inflight_small && s->adaptive_small) {
         // issue-to-landing time of the single-launch path (the search thread has been polling since the issue)
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_issue).count();
         s->small_latency = s->small_seen == 0 ? dt : 0.8 * s->small_latency + 0.2 * dt;
-        if (++s->small_seen >= 16 && s->small_latency > s->small_latency_limit) { s->pipeline_left = 2000; s->small_seen = 0; }
+        // (every rollout level is one more launch in the batch: 15 us of allowance each)
+        const double limit = s->small_latency_limit + 15e-6 * s->roll_depth;
+        if (++s->small_seen >= 16 && s->small_latency > limit) { s->pipeline_left = 2000; s->small_seen = 0; }
     }
     if (src == s) { s->inflight_small = false; s->inflight_zero_copy = false; }
     for (int i = 0; i < B; ++i) {
         const int sid = batch[i];
         s->cache_off[sid] = (int64_t)s->recs.size();
-        int cnt = 0, evals = 0;
-        for (int p = 0; p < M; ++p) {
-            const size_t k = (first + (size_t)i) * M + p;
-            const unsigned char f = pv.flags[k];
-            if (!(f & SMPLX_F_INACTIVE)) ++evals;
-            if (!(f & SMPLX_F_VALID)) continue;
-            smplx_space::Rec r;
-            r.cost = s->actions.dev.cost[p];
-            r.h = pv.h[k];
-            r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
-            r.known = s->d_table ? pv.id[k] : -1;
-            r.prim = p;
-            s->recs.push_back(r);
-            s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
-            s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
-            ++cnt;
-        }
-        s->cache_cnt[sid] = cnt;
+        int evals = 0;
+        s->cache_cnt[sid] = ingest_row(s, pv, first + (size_t)i, &evals);
         s->eval_count[sid] = evals;
         s->gpu_evals += evals;
     }
+    // N2: the rollout rows below this query's real rows
+    const smplx_space::RollPlan* rp = roll ? roll : (src == s && !view ? &s->inflight_roll : nullptr);
+    if (rp && rp->extra() > 0)
+        for (int i = 0; i < B; ++i) ingest_rollouts(s, pv, *rp, (int)first + i, batch[i]);
+    if (src == s && !view) s->inflight_roll = smplx_space::RollPlan();
     // child speculation: the extra rows behind the real states hold the successors of the first state's would-be children.
     // They are NOT ingested here: the parent is committed right after this (it is the state the search is waiting for),
     // before another batch can overwrite the pinned output block, and only the rows of children that are really created
@@ -1080,6 +1201,16 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
             if (sid < 0) {
                 sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
                 if (s->spec_parent == id) attach_speculated_child(s, sid, r.prim, &s->qs[(size_t)sid * s->N]);
+                // N2: the device continued from exactly this record (same joint values): its rows are the new state's
+                for (int32_t node = s->ph_head[id]; node >= 0; node = s->ph[node].next) {
+                    if (s->ph[node].prim != r.prim) continue;
+                    s->cache_off[sid] = s->ph[node].rec_off;
+                    s->cache_cnt[sid] = s->ph[node].cnt;
+                    s->eval_count[sid] = s->ph[node].evals;
+                    s->ph_head[sid] = s->ph[node].child;
+                    ++s->roll_attached;
+                    break;
+                }
             }
             s->done_succ.push_back(r.goal ? 0 : sid);
             s->done_cost.push_back(r.cost);
@@ -1256,6 +1387,12 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if (params->reserved & 4) s->small_batch_max = 0;
     if (const char* e = getenv("SMPLX_SPEC_CHILDREN")) s->spec_children = e[0] != '0';
     if (const char* e = getenv("SMPLX_SMALL_ZERO_COPY")) s->small_zero_copy = e[0] != '0';
+    if (const char* e = getenv("SMPLX_SMALL_MAX")) s->small_batch_max = std::max(0, atoi(e));
+    s->dbg_birth_on = getenv("SMPLX_DEBUG_TIMING") != nullptr;
+    if (const char* e = getenv("SMPLX_ROLLOUT_DEPTH")) s->roll_depth = std::max(0, std::min(8, atoi(e)));
+    if (const char* e = getenv("SMPLX_ROLLOUT_BEAM")) s->roll_beam = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = getenv("SMPLX_ROLLOUT_ROWS")) s->roll_rows = std::max(1, std::min(4096, atoi(e)));
+    if (const char* e = getenv("SMPLX_ROLLOUT_W")) { s->roll_w = std::max(0, std::min(1000, atoi(e))); s->roll_w_fixed = true; }
     if (const char* e = getenv("SMPLX_SMALL_KERNEL")) {
         if (!std::strcmp(e, "always")) s->small_latency_limit = 1.0;
         else if (!std::strcmp(e, "never")) s->small_batch_max = 0;
@@ -2046,6 +2183,12 @@ struct Search {
                     if (hid > 0 && sp->cache_off[hid] == -1 && sp->done_off[hid] < 0) sp->hint.push_back(hid);
                 }
                 ++sp->cache_misses;
+                if (sp->dbg_birth_on && (size_t)m < sp->dbg_birth.size()) {
+                    const long age = (long)sp->expansion_log.size() - sp->dbg_birth[m];
+                    int b = 0;
+                    for (long a = age; a > 1 && b < 7; a >>= 2) ++b;   // 0-1, 2-7, 8-31, 32-127, ...
+                    ++sp->dbg_age_hist[b];
+                }
                 miss_id = m;
                 if (!defer_issue) {
                     error = issue_batch(sp, m);
@@ -2102,6 +2245,7 @@ struct Search {
                     reorder_open();
                     incons.clear();
                 }
+                if (!sp->roll_w_fixed) sp->roll_w = std::max(1, (int)curr_eps);   // N2: the device ranks children by cost + eps*h too
                 phase = 2;
                 num_before = num;
             }
@@ -2303,7 +2447,10 @@ static inline void cpu_relax() { __builtin_ia32_pause(); }
 int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* done, double* t_done,
                   std::chrono::steady_clock::time_point t0)
 {
-    enum { kSets = 8, kInFlight = 4, kSmallZeroCopyMax = 16 };
+    enum { kSets = 8, kInFlight = 4 };
+    int small_zero_copy_max = 16;
+    if (const char* e = getenv("SMPLX_MULTI_SMALL_MAX")) small_zero_copy_max = std::max(0, atoi(e));
+    const bool small_device = getenv("SMPLX_MULTI_SMALL_DEVICE") != nullptr;   // A/B switch: single launch with device buffers + DMA
     smplx_space* lead = spaces[0];
     const int N = lead->N, M = lead->M;
     std::vector<std::atomic<int>> qstate(nq);
@@ -2466,7 +2613,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     // rocprofv3 on MI355X, 128 queries: the single-launch kernel with its results written straight to host
                     // memory averages 152 us at ~100 states (it is built for the handful of states a lone query misses
                     // on: 33 us), the four pipeline kernels together 36 us
-                    if (B <= kSmallZeroCopyMax && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
+                    if (B <= small_zero_copy_max && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
                         // one launch, no copies: parents, query indices and results live in pinned host memory
                         ZeroCopy zc;
                         zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h; zc.id = Nf.pv.id;
@@ -2478,7 +2625,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         HIP_TRY(hipMemcpyAsync(Nf.b_stateq.p, Nf.p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, Nf.stream));
                         k5.items = (const int32_t*)(Nf.b_q.p + total * N);
                         if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
-                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, true, &k5))) return e;
+                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, !small_device, &k5))) return e;
                         HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));
                     }
                     HIP_TRY(hipEventRecord(Nf.done, Nf.stream));
@@ -2627,8 +2774,15 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
                 t_wait += secs(w0, now());
             }
         }
-        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs; launches: single-kernel %lld pipeline %lld\n",
-                         t_resume, t_wait, t_collect, (long long)spaces[0]->small_launches, (long long)spaces[0]->pipe_launches);
+        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs; launches: single-kernel %lld pipeline %lld; rollout rows %lld attached %lld\n",
+                         t_resume, t_wait, t_collect, (long long)spaces[0]->small_launches, (long long)spaces[0]->pipe_launches,
+                         (long long)spaces[0]->roll_rows_total, (long long)spaces[0]->roll_attached);
+        if (dbg) {
+            const int64_t* hgm = spaces[0]->dbg_age_hist;
+            fprintf(stderr, "[smplx timing] age (expansions since creation) of the states missed on: 0-1: %lld, 2-7: %lld, 8-31: %lld, 32-127: %lld, "
+                            "128-511: %lld, 512-2047: %lld, more: %lld\n", (long long)hgm[0], (long long)hgm[1], (long long)hgm[2], (long long)hgm[3],
+                    (long long)hgm[4], (long long)hgm[5], (long long)(hgm[6] + hgm[7]));
+        }
     }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (wall_seconds) *wall_seconds = wall;

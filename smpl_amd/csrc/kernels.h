@@ -57,7 +57,7 @@ __global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int
                               double* out_q, int* out_h, int* out_cost, int* out_lookups, int* deferred_count,
                               const SmplxSpaceDev* const* stab, const unsigned short* state_q, unsigned char* host_flags,
                               int* host_coord, double* host_q, int* host_h, int* out_id, int* host_id, const int* ins_items,
-                              int n_ins);
+                              int n_ins, SmplxRollDev roll);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

@@ -419,6 +419,8 @@ struct ChainState {
     // squared cell distance the lookup returns
     double Tp[12];
     int pd2;
+    // the squared cell distance at every tree's root, looked up in one sweep (const_chain_issue)
+    int pd2s[CM_NT > 0 ? CM_NT : 1];
 };
 
 template <int T_, int K, int KEND>
@@ -492,7 +494,7 @@ __device__ __forceinline__ void apply_joint_const(double q, double T[12])
 // does not clear hands over to the generic traversal at its children (larger child first, as check_tree does), with
 // the link transform kept in C.Tp.  The order of the lookups -- and so the tally, also of a colliding configuration --
 // is unchanged: tree k is resolved before tree k+1 is issued.
-template <int T_>
+template <int T_, bool Known = false>
 __device__ __forceinline__ void issue_root(const SmplxGridDev& g, ChainState& C, int& lookups, double root_p[3])
 {
     constexpr double cx = CM_ROOT_CX[T_], cy = CM_ROOT_CY[T_], cz = CM_ROOT_CZ[T_];
@@ -510,7 +512,8 @@ __device__ __forceinline__ void issue_root(const SmplxGridDev& g, ChainState& C,
 #ifdef ABL_NO_LOOKUP
     C.pd2 = 60000 + (int)(root_p[0] * 0.0);
 #else
-    C.pd2 = grid_d2(g, root_p);
+    if constexpr (Known) C.pd2 = C.pd2s[T_];   // second walk: the sweep already fetched it
+    else C.pd2 = grid_d2(g, root_p);
 #endif
     if constexpr (CM_ROOT_LEFT[T_] >= 0) {
 #pragma unroll
@@ -561,7 +564,7 @@ __device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, con
 }
 
 // PT = the tree whose root lookup was issued at an earlier joint and has not been looked at yet (-1: none)
-template <int J, int PT>
+template <int J, int PT, bool Known = false>
 __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                             ChainState& C, int& lookups)
 {
@@ -590,16 +593,16 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
 #ifdef ABL_NO_TREES
             rp[0] = C.T[3]; rp[1] = C.T[7]; rp[2] = C.T[11];
 #else
-            issue_root<tree>(g, C, lookups, rp);
+            issue_root<tree, Known>(g, C, lookups, rp);
 #endif
             constexpr int slot = CM_ROOT_SLOT[tree];
             if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
 #ifndef ABL_NO_PAIRS
             const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
 #endif
-            return const_chain<J + 1, tree>(M, L, g, C, lookups);
+            return const_chain<J + 1, tree, Known>(M, L, g, C, lookups);
         } else {
-            return const_chain<J + 1, -1>(M, L, g, C, lookups);
+            return const_chain<J + 1, -1, Known>(M, L, g, C, lookups);
         }
     } else {
         if constexpr (PT >= 0) {
@@ -611,6 +614,82 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         } else {
             return true;
         }
+    }
+}
+
+// ---- the sweep: FK over the whole chain with EVERY tree's root lookup in flight at once ----
+// Walking the chain tree by tree (const_chain) puts one L2/HBM round trip per tree on a wave's critical path -- about
+// 13 dependent gathers per configuration, 61 % of the wave's cycles waiting (rocprofv3, round 1) -- and at B = 4096 there
+// are only ~2 waves per SIMD to hide them behind.  So the chain is walked once WITHOUT looking at any answer: all root
+// positions are computed and all root lookups issued back to back.  Then the answers are read in chain order
+// (const_scan): every root clears -> done, the tally is the number of trees; the first root that fails is a leaf ->
+// collision, the tally is the trees up to it; otherwise some tree has to be descended into, and the chain is walked a
+// second time in the old way (const_chain<.., Known = true>: root answers from registers, descents with the link
+// transform at hand).  Verdict, early-exit point and lookup tally are those of the one-by-one walk.
+template <int J>
+__device__ __forceinline__ void const_chain_issue(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                                  ChainState& C)
+{
+    if constexpr (J < CM_NJ) {
+        constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J], tree = CM_TREE[J];
+        if constexpr (src >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) C.T[i] = lds_d(L, L.slot_base + 12 * src + i);
+        }
+        double q = 0.0;
+        if constexpr (var >= 0) q = C.q[var];
+        if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J, src == SMPLX_SRC_ROOT>(q, C.T);
+        else apply_joint(&M->joints[J], q, C.T, src == SMPLX_SRC_ROOT);
+        if constexpr (save >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = C.T[i];
+        }
+        if constexpr (tree >= 0) {
+            constexpr double cx = CM_ROOT_CX[tree], cy = CM_ROOT_CY[tree], cz = CM_ROOT_CZ[tree];
+            double rp[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {   // the expression of issue_root
+                double acc = 0.0;
+                bool have = false;
+                if constexpr (cx != 0.0) { acc = C.T[4 * i + 0] * cx; have = true; }
+                if constexpr (cy != 0.0) { acc = have ? acc + C.T[4 * i + 1] * cy : C.T[4 * i + 1] * cy; have = true; }
+                if constexpr (cz != 0.0) { acc = have ? acc + C.T[4 * i + 2] * cz : C.T[4 * i + 2] * cz; have = true; }
+                rp[i] = have ? acc + C.T[4 * i + 3] : C.T[4 * i + 3];
+            }
+            C.pd2s[tree] = grid_d2(g, rp);
+            constexpr int slot = CM_ROOT_SLOT[tree];
+            if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
+            const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
+        }
+        const_chain_issue<J + 1>(M, L, g, C);
+    }
+}
+
+// trees on joints 0 .. J (inclusive)
+template <int J>
+constexpr int cm_trees_through()
+{
+    int n = 0;
+    for (int j = 0; j <= J && j < CM_NJ; ++j) n += CM_TREE[j] >= 0 ? 1 : 0;
+    return n;
+}
+
+// 1: every root clears; 0: the first root that does not clear is a leaf (collision); 2: a tree has to be descended into
+template <int J>
+__device__ __forceinline__ int const_scan(const ChainState& C, int& tally)
+{
+    if constexpr (J < CM_NJ) {
+        constexpr int tree = CM_TREE[J];
+        if constexpr (tree >= 0) {
+            if (C.pd2s[tree] < CM_ROOT_THR[tree]) {
+                if constexpr (CM_ROOT_LEFT[tree] < 0) { tally = cm_trees_through<J>(); return 0; }
+                else return 2;
+            }
+        }
+        return const_scan<J + 1>(C, tally);
+    } else {
+        tally = cm_trees_through<CM_NJ - 1>();
+        return 1;
     }
 }
 
@@ -639,8 +718,9 @@ __device__ __forceinline__ void const_planning_chain(const ModelLds* __restrict_
 // CollisionSpace::isStateValid for one configuration (collision_space.cpp:532-536 ->
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
-__device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
-                                             const EdgeRef& e, int& lookups)
+// the configuration's joint values are already staged in the thread's LDS slots (stage_config or the caller itself)
+__device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                                    const EdgeRef& e, int& lookups)
 {
     double T[12];
 #pragma unroll
@@ -651,7 +731,6 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
 #ifdef ABL_NO_FK
     lookups += (int)e.alpha; return true;
 #endif
-    stage_config(M, L, e);
 #ifdef SMPLX_CONST_MODEL
     {
         ChainState C;
@@ -661,7 +740,23 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
         for (int v = 0; v < CM_NV; ++v) C.q[v] = lds_d(L, L.q_base + v);
         C.pair_hit = false; C.recheck_all = false; C.pending = 0; C.npending = 0;
         C.pd2 = 0;
+#if !defined(SMPLX_CHAIN_SWEEP) || defined(ABL_NO_TREES) || defined(ABL_NO_LOOKUP)   // measured: the sweep is SLOWER (27.2 vs 23.7 us), see its comment
         if (!const_chain<0, -1>(M, L, g, C, lookups)) return false;
+#else
+        const_chain_issue<0>(M, L, g, C);
+        int tally = 0;
+        const int verdict = const_scan<0>(C, tally);
+        if (verdict == 0) { lookups += tally; return false; }
+        if (verdict == 1) {
+            lookups += tally;
+        } else {
+            // second walk, with the descents (the pair bookkeeping is redone from scratch: same inputs, same outcome)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) C.T[i] = 0.0;
+            C.pair_hit = false; C.recheck_all = false; C.pending = 0; C.npending = 0;
+            if (!const_chain<0, -1, true>(M, L, g, C, lookups)) return false;
+        }
+#endif
         pair_hit = C.pair_hit; recheck_all = C.recheck_all; pending = C.pending; npending = C.npending;
     }
     const int nj = 0;
@@ -753,6 +848,15 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
         if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
     }
     return !pair_hit;
+}
+
+__device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                             const EdgeRef& e, int& lookups)
+{
+#ifndef ABL_NO_FK
+    stage_config(M, L, e);
+#endif
+    return config_valid_staged(M, L, g, e, lookups);
 }
 
 // CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
@@ -1445,6 +1549,65 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     }
     const long long total = (long long)B + pre[SMPLX_WORK_SHARDS];
     if ((long long)blockIdx.x * BLOCK >= total) return;   // whole block idle: skip staging the model
+#ifdef SMPLX_CONST_MODEL
+    // Per-robot build: the launch covers every item (engine.hip sizes the grid for B + 3 B M items and k_pipe_setup never
+    // lists more), one item per thread.  A block's life is a chain of dependent memory round trips of ~1 us each --
+    // counts, model header, model bytes, work item, joint values -- in front of ~10 us of work: the item and the joint
+    // values of its edge are fetched BEFORE the model is staged, so that they travel together with the model bytes
+    // (5 round trips -> 3).
+    if (total <= (long long)gridDim.x * BLOCK) {
+        const int nprims = S->actions.nprims;
+        constexpr int nv = CM_NV;
+        const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        unsigned long long it = SMPLX_WORK_BLANK;
+        if (i >= B && i < total) {
+            const int li = (int)(i - B);
+            int sh = 0;
+#pragma unroll
+            for (int k = 1; k < SMPLX_WORK_SHARDS; ++k) sh += (li >= pre[k]) ? 1 : 0;
+            it = work[(size_t)sh * shard_cap + (li - pre[sh])];
+        }
+        const bool is_state = i < B, is_item = it != SMPLX_WORK_BLANK;
+        const long long edge = (long long)(it & 0xFFFFFFFFull);
+        const int wp = (int)((it >> 32) & 0xFFFF);
+        const int W = (int)(it >> 48);
+        double qs[CM_NV], qf[CM_NV];
+        if (is_state || is_item) {
+            const long long si = is_state ? i : edge / nprims;
+            const double* ps = Q + (refs ? refs[si] : (int64_t)si) * nv;
+            const double* pf = is_state ? ps : out_q + edge * nv;
+#pragma unroll
+            for (int v = 0; v < nv; ++v) { qs[v] = ps[v]; qf[v] = pf[v]; }
+        }
+        ModelLds Mv;
+        ThreadLds L = setup_lds(S, smem, &Mv);
+        const ModelLds* M = &Mv;
+        const SmplxGridDev grid = S->grid;
+        if (!(is_state || is_item)) return;
+        EdgeRef e;
+        e.start = nullptr; e.finish = nullptr;   // config_valid_staged never dereferences them
+        e.alpha = is_state ? 0.0 : (double)wp * (1.0 / (double)(W - 1));
+        int lk = 0;
+#ifndef ABL_NO_FK
+#pragma unroll
+        for (int v = 0; v < nv; ++v) {   // stage_config
+            const double sv = qs[v];
+            double q = sv;
+            if (e.alpha != 0.0) q = sv + e.alpha * edge_diff(M, v, sv, qf[v]);
+            lds_d(L, L.q_base + v) = q;
+        }
+#endif
+        const bool ok = config_valid_staged(M, L, grid, e, lk);
+        if (is_state) {
+            state_lookups[i] = lk;
+            if (!ok) state_bad[i] = 1;
+        } else {
+            atomicAdd(&edge_lookups[edge], lk);
+            if (!ok) edge_bad[edge] = 1;
+        }
+        return;
+    }
+#endif
     ModelLds Mv;
     ThreadLds L = setup_lds(S, smem, &Mv);
     const ModelLds* M = &Mv;
@@ -1663,7 +1826,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
               const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
               unsigned char* __restrict__ host_flags, int* __restrict__ host_coord, double* __restrict__ host_q,
               int* __restrict__ host_h, int* __restrict__ out_id, int* __restrict__ host_id,
-              const int* __restrict__ ins_items, int n_ins)
+              const int* __restrict__ ins_items, int n_ins, SmplxRollDev roll)
 {
     // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
     // as a few KB of PCIe stores than as DMA copies); Q may itself be pinned host memory -- the parent's
@@ -1682,14 +1845,61 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
-    const int si = blockIdx.x;
+    // rows: block b of this launch produces row roll.row0 + b of the dense outputs (row0 = 0 outside a rollout)
+    const long long si = (long long)roll.row0 + blockIdx.x;
     const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
     const SmplxBfsDev bfs = Sq->bfs;
     const int nprims = A.nprims, nv = MV_NVARS(M);
     const int t = threadIdx.x;
     const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
     const int book0 = (ncfg + 63) / 64 * 64;                  // first lane of the bookkeeping wave
-    if (t < nv) s_parent[t] = Q[(refs ? refs[si] : (int64_t)si) * nv + t];
+    long long parent_at = refs ? refs[si] : (int64_t)si;      // where the parent's joint values sit in Q (units of nv)
+    if (roll.on) {
+        // Rollout row (N2: expansion continued on the device): the parent is a SUCCESSOR evaluated by an earlier launch
+        // of this batch -- the (rank+1)-th best valid, non-goal edge of row `src` under cost + w*h (ties: lower
+        // primitive index) -- read from the dense outputs in HBM.  Which edge was taken is written to out_sel; a row
+        // with nothing to continue from marks all its edges inactive.
+        const long long src = (long long)roll.base + (roll.mod > 0 ? (int)(blockIdx.x % (unsigned)roll.mod) : (int)blockIdx.x);
+        const int rank = roll.rank_div > 0 ? (int)(blockIdx.x / (unsigned)roll.rank_div) : 0;
+        __shared__ long long s_key[SMPLX_MAX_PRIMS];
+        __shared__ int s_sel;
+        if (t < nprims) {
+            const unsigned char f = out_flags[src * nprims + t];
+            long long key = -1;
+            if ((f & SMPLX_F_VALID) && !(f & SMPLX_F_GOAL))
+                key = ((long long)A.cost[t] + (long long)roll.w * (long long)out_h[src * nprims + t]) * SMPLX_MAX_PRIMS + t;
+            s_key[t] = key;
+        }
+        __syncthreads();
+        if (t == 0) {
+            long long last = -1;
+            int best = -1;
+            for (int r = 0; r <= rank; ++r) {
+                long long bk = -1;
+                best = -1;
+                for (int p = 0; p < nprims; ++p) {
+                    const long long key = s_key[p];
+                    if (key > last && (bk < 0 || key < bk)) { bk = key; best = p; }
+                }
+                if (best < 0) break;
+                last = bk;
+            }
+            s_sel = best;
+            const int sel = best < 0 ? -1 : (int)(src * nprims + best);
+            roll.out_sel[si] = sel;
+            if (roll.host_sel) roll.host_sel[si] = sel;
+        }
+        __syncthreads();
+        if (s_sel < 0) {
+            if (t < nprims) {
+                out_flags[si * nprims + t] = SMPLX_F_INACTIVE;
+                if (host_flags) host_flags[si * nprims + t] = SMPLX_F_INACTIVE;
+            }
+            return;
+        }
+        parent_at = src * nprims + s_sel;
+    }
+    if (t < nv) s_parent[t] = Q[parent_at * nv + t];
     if (t < nprims) { s_edge_bad[t] = 0; s_edge_lk[t] = 0; }
     __syncthreads();
     const double* parent = s_parent;
