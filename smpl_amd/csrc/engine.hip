@@ -266,6 +266,9 @@ struct smplx_space {
     struct RollPlan { int B = 0, R = 0, K = 0, D = 0; int extra() const { return R * K * D; } };
     RollPlan inflight_roll;
     int64_t roll_rows_total = 0, roll_attached = 0;
+    int32_t* small_trace = nullptr;          // pinned, 8 ints (SMPLX_DEBUG_TIMING): see SMALL_MARK in kernels.hip
+    double small_trace_sum[6] = {0, 0, 0, 0, 0, 0};
+    int64_t small_trace_n = 0;
     // SMPLX_DEBUG_TIMING: how old (in expansions) the states are that the search misses on
     bool dbg_birth_on = false;
     std::vector<int32_t> dbg_birth;
@@ -300,11 +303,11 @@ struct smplx_space {
     std::vector<int32_t> inflight;
     hipEvent_t batch_done = nullptr;
     bool inflight_zero_copy = false;   // the batch in flight wrote its results straight into the pinned host buffers
-    // Small batches: the single-launch kernel costs the host one launch, the pipeline several launches and copies
-    // (about 30 us more host time per batch) -- but a sparse stream of single 30 us kernels can leave the GPU at its
-    // idle clock (640 MHz seen on some boxes of the pool: 107 us per batch instead of 33 us), which the busier pipeline
-    // path does not.  Both give the same bytes, so the engine watches the issue-to-landing time of the single-launch
-    // path and sits out 2000 batches on the pipeline path whenever its average exceeds 70 us.
+    // Small batches: the single-launch kernel costs the host one launch (27 us issue-to-landing for the handful of states
+    // a lone query misses on), the pipeline several launches and copies (~34 us).  Both give the same bytes.  The engine
+    // watches the issue-to-landing time of the single-launch path and sits out 2000 batches on the pipeline path whenever
+    // its moving average exceeds 70 us: a safety net from the time the kernel checked the snap-to-goal edge of every
+    // state ungated (105 us per launch; fixed, see k_small_batch) -- it costs nothing when the kernel behaves.
     std::chrono::steady_clock::time_point t_issue;
     bool inflight_small = false;
     bool adaptive_small = false;  // only a lone query measures: with several queries per thread the landing time includes their turns
@@ -652,6 +655,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     SmplxRollDev noroll;
     std::memset(&noroll, 0, sizeof(noroll));
+    noroll.host_sel = s->small_trace;   // -DSMPLX_SMALL_TRACE builds only: phase clock of block 0
     if (!force_pipeline && !s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
         !s->tiny_work_list && s->pipeline_left == 0) {
         ++s->small_launches;
@@ -1099,6 +1103,11 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         const double limit = s->small_latency_limit + 15e-6 * s->roll_depth;
         if (++s->small_seen >= 16 && s->small_latency > limit) { s->pipeline_left = 2000; s->small_seen = 0; }
     }
+    if (src == s && s->inflight_small && s->small_trace && s->small_trace[5] != 0) {
+        for (int k = 1; k < 6; ++k) s->small_trace_sum[k] += (double)(uint32_t)(s->small_trace[k] - s->small_trace[k - 1]) * 0.01;   // us
+        ++s->small_trace_n;
+        s->small_trace[5] = 0;
+    }
     if (src == s) { s->inflight_small = false; s->inflight_zero_copy = false; }
     for (int i = 0; i < B; ++i) {
         const int sid = batch[i];
@@ -1389,6 +1398,8 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if (const char* e = getenv("SMPLX_SMALL_ZERO_COPY")) s->small_zero_copy = e[0] != '0';
     if (const char* e = getenv("SMPLX_SMALL_MAX")) s->small_batch_max = std::max(0, atoi(e));
     s->dbg_birth_on = getenv("SMPLX_DEBUG_TIMING") != nullptr;
+    if (s->dbg_birth_on && hipHostMalloc((void**)&s->small_trace, 8 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess)
+        std::memset(s->small_trace, 0, 8 * sizeof(int32_t));
     if (const char* e = getenv("SMPLX_ROLLOUT_DEPTH")) s->roll_depth = std::max(0, std::min(8, atoi(e)));
     if (const char* e = getenv("SMPLX_ROLLOUT_BEAM")) s->roll_beam = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("SMPLX_ROLLOUT_ROWS")) s->roll_rows = std::max(1, std::min(4096, atoi(e)));
@@ -1504,6 +1515,7 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_brick_flags) (void)hipFree(s->d_brick_flags);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->d_table) (void)hipFree(s->d_table);
+    if (s->small_trace) (void)hipHostFree(s->small_trace);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -2777,6 +2789,12 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs; launches: single-kernel %lld pipeline %lld; rollout rows %lld attached %lld\n",
                          t_resume, t_wait, t_collect, (long long)spaces[0]->small_launches, (long long)spaces[0]->pipe_launches,
                          (long long)spaces[0]->roll_rows_total, (long long)spaces[0]->roll_attached);
+        if (dbg && spaces[0]->small_trace_n > 0) {
+            const double n = (double)spaces[0]->small_trace_n;
+            const double* t = spaces[0]->small_trace_sum;
+            fprintf(stderr, "[smplx timing] k_small_batch block 0 (us): stage model %.2f, parent %.2f, successors+gate %.2f, waypoints %.2f, verdicts+stores %.2f\n",
+                    t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
+        }
         if (dbg) {
             const int64_t* hgm = spaces[0]->dbg_age_hist;
             fprintf(stderr, "[smplx timing] age (expansions since creation) of the states missed on: 0-1: %lld, 2-7: %lld, 8-31: %lld, 32-127: %lld, "

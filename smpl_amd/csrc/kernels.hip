@@ -1818,6 +1818,14 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 // ---------------------------------------------------------------------------------------------
 #define SMPLX_SMALL_LANES 7   // waypoint lanes per edge
 
+// -DSMPLX_SMALL_TRACE (SMPLX_RTC_DEFINES): thread 0 of block 0 leaves the 100 MHz wall clock at each phase boundary in
+// the pinned buffer passed through roll.host_sel (engine.hip prints the averages under SMPLX_DEBUG_TIMING)
+#ifdef SMPLX_SMALL_TRACE
+#define SMALL_MARK(k) do { if (!roll.on && roll.host_sel && blockIdx.x == 0 && threadIdx.x == 0) roll.host_sel[k] = (int)wall_clock64(); } while (0)
+#else
+#define SMALL_MARK(k) do { } while (0)
+#endif
+
 extern "C" __global__ void __launch_bounds__(512)
 k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
               double* __restrict__ goal_dist_out, unsigned char* __restrict__ state_bad_out, int* __restrict__ state_lookups_out,
@@ -1839,9 +1847,11 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     __shared__ int s_edge_bad[SMPLX_MAX_PRIMS], s_edge_lk[SMPLX_MAX_PRIMS];
     (void)deferred_count;
     if (n_ins > 0 && table_insert_block(S, stab, ins_items, n_ins, B)) return;   // K5: see k_pipe_prep
+    SMALL_MARK(0);
     const int nth = blockDim.x;
     ModelLds Mv;
     ThreadLds L = setup_lds(S, smem, &Mv, nth);
+    SMALL_MARK(1);
     const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
@@ -1902,6 +1912,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     if (t < nv) s_parent[t] = Q[parent_at * nv + t];
     if (t < nprims) { s_edge_bad[t] = 0; s_edge_lk[t] = 0; }
     __syncthreads();
+    SMALL_MARK(2);
     const double* parent = s_parent;
 
     // ---- bookkeeping wave, first half: successor joint values of every primitive -> LDS and out_q ----
@@ -1951,6 +1962,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         goal_dist_out[si] = gd;
     }
     __syncthreads();   // every lane of every edge can read its successor's joint values and the gate from LDS
+    SMALL_MARK(3);
 
     int h = 0, is_goal = 0, early_id = -1, W = 0;
     bool limits_ok = false;
@@ -2039,6 +2051,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         }
     }
     __syncthreads();   // the waypoint verdicts and the state's own check have landed in LDS
+    SMALL_MARK(4);
 
     // ---- bookkeeping lanes: the verdict of their edge ----
     if (book) {
@@ -2080,6 +2093,10 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
             }
         }
     }
+#ifdef SMPLX_SMALL_TRACE
+    __syncthreads();
+    SMALL_MARK(5);
+#endif
 }
 
 extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it

@@ -329,3 +329,54 @@ def test_child_speculation_switch_gives_the_same_search(small_cfg, monkeypatch):
             assert r["committed_succ_evals"] == e["succ_evals"]
             misses[(env, no_small)] = r["cache_misses"]
     assert misses[("1", False)] < misses[("0", False)] and misses[("1", True)] < misses[("0", True)]
+
+
+def test_rollout_rows_give_the_same_search(small_cfg, monkeypatch):
+    """N2, SMPLX_ROLLOUT_DEPTH/_BEAM: every batch also evaluates, on the device, the best successors of its states and a
+    chain of best successors below each (parents read from the batch's own outputs in HBM); the rows wait as phantom
+    nodes and become a state's cache entry when the state is created from the very record the device continued from.
+    Same search as without and as the oracle's, fewer misses, behind the single-launch kernel and behind the pipeline."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); o.set_start(cfg.start)
+    o.search_params(5.0, 1.0, 1.0, True, True, 6000, 3000)
+    e = o.plan()
+    misses = {}
+    for depth, beam in ((0, 1), (2, 2), (1, 4)):
+        monkeypatch.setenv("SMPLX_ROLLOUT_DEPTH", str(depth))
+        monkeypatch.setenv("SMPLX_ROLLOUT_BEAM", str(beam))
+        for no_small in (False, True):
+            s = capi.Space.from_config(cfg, batch_states=256, no_small_kernel=no_small)
+            s.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_start(cfg.start)
+            r = s.plan(5.0, 1.0, 1.0, True, True, 6000, 3000)
+            assert r["cost"] == e["cost"] and np.array_equal(r["expansion_log"], e["expansion_log"]) and np.array_equal(r["path"], e["path"])
+            assert r["committed_succ_evals"] == e["succ_evals"]
+            assert s.num_states() == o.num_states()
+            misses[(depth, beam, no_small)] = r["cache_misses"]
+    for no_small in (False, True):
+        assert misses[(2, 2, no_small)] < misses[(0, 1, no_small)] and misses[(1, 4, no_small)] < misses[(0, 1, no_small)]
+
+
+def test_root_lookup_sweep_build_gives_the_same_results(small_cfg, monkeypatch):
+    """-DSMPLX_CHAIN_SWEEP (per-robot build): all tree-root lookups of a configuration in flight at once, answers read in
+    chain order, second walk only where a tree has to be descended into.  Measured slower than the one-by-one walk (so
+    it is not the default) but it must give the same verdicts and the same lookup tallies."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    monkeypatch.setenv("SMPLX_RTC_DEFINES", "-DSMPLX_CHAIN_SWEEP")
+    s = capi.Space.from_config(cfg, batch_states=256)
+    ok, note = s.specialized()
+    if not ok:
+        pytest.skip("generic kernels in use: the sweep only exists in the per-robot build (" + note + ")")
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    _same_search(o, s, 5.0, 3000, 3000)
+    Q = scenes.random_states(scenes.ARM7_LIMITS, 96, 5)
+    o.set_order(chain=True)
+    _compare_batch(o, s, Q)
