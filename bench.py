@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--planner-expansions", type=int, default=40000)
     ap.add_argument("--queries-per-gpu", type=int, default=128, help="config-4 shard size per rank")
     ap.add_argument("--shard-expansions", type=int, default=20000, help="expansion bound per query in the shard leg")
-    ap.add_argument("--host-threads", type=int, default=12,
+    ap.add_argument("--host-threads", type=int, default=14,
                     help="worker threads of smplx_plan_multi in the shard leg (searches and commits; one more thread submits to the GPU)")
     ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
     ap.add_argument("--profile-steps", type=int, default=0,

@@ -117,9 +117,17 @@ struct CoordTable {
         }
         return h;
     }
-    int find(const int32_t* c, const std::vector<int32_t>& coords) const
+    int find(const int32_t* c, const std::vector<int32_t>& coords) const { return find_hashed(c, hash(c, N), coords); }
+    // the two dependent cache misses of a lookup (slot, then the coordinate row it names), started ahead of time
+    void prefetch_slot(uint64_t h) const { __builtin_prefetch(&slots[h & mask]); }
+    void prefetch_row(uint64_t h, const std::vector<int32_t>& coords) const
     {
-        size_t i = hash(c, N) & mask;
+        const int32_t s = slots[h & mask];
+        if (s) __builtin_prefetch(&coords[(size_t)(s - 1) * N]);
+    }
+    int find_hashed(const int32_t* c, uint64_t h, const std::vector<int32_t>& coords) const
+    {
+        size_t i = h & mask;
         while (true) {
             const int32_t s = slots[i];
             if (s == 0) return -1;
@@ -216,7 +224,7 @@ struct smplx_space {
     std::string specialize_note;   // why the per-robot build is absent, if it is
     bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
     bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
-    int small_batch_max = 256;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
+    int small_batch_max = 512;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
     double small_latency_limit = 70e-6;   // SMPLX_SMALL_KERNEL=always lifts it, =never disables the single-launch kernel
     bool small_zero_copy = true;          // SMPLX_SMALL_ZERO_COPY=0: the single-launch kernel with DMA copies instead of host-memory I/O
     DevBuf<unsigned long long> b_counters;
@@ -1201,12 +1209,22 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
         const int64_t off = s->cache_off[id];
         const int cnt = s->cache_cnt[id];
         const int64_t dof = (int64_t)s->done_succ.size();
+        // With many queries per core the tables live in DRAM: a lookup is two dependent misses (slot, coordinate row).
+        // The hashes of all records first, their slots prefetched together, then the rows the slots name: the ~14
+        // lookups of an expansion overlap instead of queueing (commit is the host's largest share of an expansion).
+        uint64_t hashes[SMPLX_MAX_PRIMS];
+        const int npre = cnt <= SMPLX_MAX_PRIMS ? cnt : 0;
+        for (int k = 0; k < npre; ++k) {
+            hashes[k] = CoordTable::hash(&s->rec_coord[(size_t)(off + k) * s->N], s->N);
+            s->table.prefetch_slot(hashes[k]);
+        }
+        for (int k = 0; k < npre; ++k) s->table.prefetch_row(hashes[k], s->coords);
         for (int k = 0; k < cnt; ++k) {
             const smplx_space::Rec r = s->recs[off + k];
             const int32_t* c = &s->rec_coord[(size_t)(off + k) * s->N];
             // K5: the device table already named the state when the batch was evaluated (it only holds committed
             // states, so a hit is final); otherwise getOrCreateState on the host table
-            int sid = r.known >= 0 ? r.known : s->table.find(c, s->coords);
+            int sid = r.known >= 0 ? r.known : (k < npre ? s->table.find_hashed(c, hashes[k], s->coords) : s->table.find(c, s->coords));
             if (sid < 0) {
                 sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
                 if (s->spec_parent == id) attach_speculated_child(s, sid, r.prim, &s->qs[(size_t)sid * s->N]);
@@ -2147,6 +2165,8 @@ struct Search {
         const int32_t* ss = succs;
         const int32_t* cc = costs;
         const unsigned int eg = st[sid].eg;
+        for (int i = 0; i < n; ++i)
+            if ((size_t)ss[i] < st.size()) __builtin_prefetch(&st[ss[i]]);   // the successors' search states, all misses at once
         for (int i = 0; i < n; ++i) {
             const int nid = ss[i];
             reinit(nid);
@@ -2460,7 +2480,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                   std::chrono::steady_clock::time_point t0)
 {
     enum { kSets = 8, kInFlight = 4 };
-    int small_zero_copy_max = 16;
+    int small_zero_copy_max = 512;
     if (const char* e = getenv("SMPLX_MULTI_SMALL_MAX")) small_zero_copy_max = std::max(0, atoi(e));
     const bool small_device = getenv("SMPLX_MULTI_SMALL_DEVICE") != nullptr;   // A/B switch: single launch with device buffers + DMA
     smplx_space* lead = spaces[0];
@@ -2482,6 +2502,8 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
     const int device = lead->device;
     int issue_percent = 45;
     if (const char* e = getenv("SMPLX_ISSUE_PERCENT")) issue_percent = std::max(1, std::min(100, atoi(e)));
+    int groups = 1;   // SMPLX_ISSUE_GROUPS: batches are formed within a group of queries (A/B switch, see the submitter)
+    if (const char* e = getenv("SMPLX_ISSUE_GROUPS")) groups = std::max(1, std::min(8, atoi(e)));
     std::vector<BatchBuffers> sets(kSets);
 
     auto fail = [&](int code, const std::string& msg) {
@@ -2491,7 +2513,8 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
 
     // worker w owns the queries q with q % nworkers == w
     auto worker = [&](int w) {
-        double t_work = 0;
+        double t_work = 0, t_ingest = 0;
+        long n_ingest = 0, n_resume = 0;
         const auto w_begin = std::chrono::steady_clock::now();
         while (remaining.load(std::memory_order_acquire) > 0 && error.load(std::memory_order_relaxed) == 0) {
             bool progressed = false;
@@ -2505,7 +2528,9 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     if (int e = collect_batch(spaces[q], lead, (size_t)row_of[q], &Bf.pv)) { fail(e, g_error); return; }
                     Bf.uncollected.fetch_sub(1, std::memory_order_acq_rel);
                     qstate[q].store(QS_RUNNABLE, std::memory_order_relaxed);
+                    if (dbg) { t_ingest += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count(); ++n_ingest; }
                 }
+                ++n_resume;
                 const int r = S[q].resume();
                 progressed = true;
                 if (S[q].error) { fail(S[q].error, g_error); return; }
@@ -2525,7 +2550,8 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         }
         if (dbg) {
             const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - w_begin).count();
-            fprintf(stderr, "[smplx timing] worker %d: search+commit+ingest %.3fs of %.3fs\n", w, t_work, tot);
+            fprintf(stderr, "[smplx timing] worker %d: search+commit+ingest %.3fs of %.3fs (ingest %.3fs in %ld landings; %ld resumes)\n", w, t_work, tot,
+                    t_ingest, n_ingest, n_resume);
         }
     };
 
@@ -2538,6 +2564,11 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         long sweeps = 0, states = 0;
         double t_issue = 0;
         int in_flight = 0, next_set = 0, oldest = 0;
+        // SMPLX_DEBUG_TIMING: how long the GPU had nothing of this shard, issue-to-landing time, depth at issue
+        double t_gpu_idle = 0, lat_sum = 0;
+        long depth_sum = 0;
+        auto idle_since = std::chrono::steady_clock::now();
+        std::chrono::steady_clock::time_point issued_at[kSets];
         while (remaining.load(std::memory_order_acquire) > 0 && error.load(std::memory_order_relaxed) == 0) {
             bool did = false;
             // retire landed batches in issue order
@@ -2549,6 +2580,11 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                 Bf.uncollected.store((int)Bf.queries.size(), std::memory_order_relaxed);
                 for (int q : Bf.queries) qstate[q].store(QS_LANDED, std::memory_order_release);
                 Bf.in_flight = false;
+                if (dbg) {
+                    const auto nowt = std::chrono::steady_clock::now();
+                    lat_sum += std::chrono::duration<double>(nowt - issued_at[oldest]).count();
+                    if (in_flight == 1) idle_since = nowt;
+                }
                 oldest = (oldest + 1) % kSets;
                 --in_flight;
                 did = true;
@@ -2562,14 +2598,25 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                 // moment it appears gives many small batches (27 queries each with 128 live) and a query then waits for
                 // ~5 batch times per miss.  So a batch is issued when about half of the live queries are waiting:
                 // one half of them is on the GPU while the workers run the other half.
-                const int live = remaining.load(std::memory_order_acquire);
-                int pending = 0;
-                for (int q = 0; q < nq; ++q) pending += qstate[q].load(std::memory_order_acquire) == QS_REQUESTED ? 1 : 0;
-                const int threshold = std::max(1, (live * issue_percent + 99) / 100);
+                int live_g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pend_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int q = 0; q < nq; ++q) {
+                    if (done[q]) continue;
+                    const int g = (q / nworkers) % groups;
+                    ++live_g[g];
+                    pend_g[g] += qstate[q].load(std::memory_order_acquire) == QS_REQUESTED ? 1 : 0;
+                }
+                // the group closest to its threshold (one group: every live query)
+                int pick = -1;
+                for (int g = 0; g < groups; ++g) {
+                    if (live_g[g] == 0 || pend_g[g] == 0) continue;
+                    if (pend_g[g] < std::max(1, (live_g[g] * issue_percent + 99) / 100)) continue;
+                    if (pick < 0 || (long)pend_g[g] * live_g[pick] > (long)pend_g[pick] * live_g[g]) pick = g;
+                }
                 Nf.queries.clear();
                 size_t total = 0;
-                if (pending >= threshold) {
+                if (pick >= 0) {
                     for (int q = 0; q < nq; ++q) {
+                        if ((q / nworkers) % groups != pick) continue;
                         if (qstate[q].load(std::memory_order_acquire) != QS_REQUESTED) continue;
                         row_of[q] = (long)total;
                         set_of[q] = next_set;
@@ -2622,9 +2669,11 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         k5.n_items = (int)(Nf.ins_items.size() / ((size_t)N + 2));
                         item_doubles = stage_items(Nf.p_q, total * N, Nf.ins_items);
                     }
-                    // rocprofv3 on MI355X, 128 queries: the single-launch kernel with its results written straight to host
-                    // memory averages 152 us at ~100 states (it is built for the handful of states a lone query misses
-                    // on: 33 us), the four pipeline kernels together 36 us
+                    // Batches of up to 512 states: ONE launch, results written straight to pinned host memory.  Against the
+                    // pipeline (two uploads, four kernels, one download: seven runtime calls) the submitter spends 34
+                    // instead of 48 us per batch and a batch lands after 78 instead of 113 us: shard +8..17 % (same box,
+                    // A/B).  (Round 2 first measured the opposite -- 152 us per launch at ~100 states -- because the
+                    // kernel then checked the snap-to-goal edge of every state ungated, see k_small_batch.)
                     if (B <= small_zero_copy_max && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
                         // one launch, no copies: parents, query indices and results live in pinned host memory
                         ZeroCopy zc;
@@ -2641,6 +2690,11 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));
                     }
                     HIP_TRY(hipEventRecord(Nf.done, Nf.stream));
+                    if (dbg) {
+                        issued_at[next_set] = i0;
+                        depth_sum += in_flight;
+                        if (in_flight == 0) t_gpu_idle += std::chrono::duration<double>(i0 - idle_since).count();
+                    }
                     Nf.in_flight = true;
                     Nf.total = total;
                     ++in_flight;
@@ -2655,8 +2709,10 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         }
         // drain what is still in flight (only on error paths: with no live query nothing is pending)
         for (BatchBuffers& Bf : sets) if (Bf.stream) (void)hipStreamSynchronize(Bf.stream);
-        if (dbg) fprintf(stderr, "[smplx timing] submitter: %ld batches, %.1f states/batch; issuing %.3fs (pack + enqueue)\n",
-                         sweeps, sweeps ? (double)states / sweeps : 0.0, t_issue);
+        if (dbg) fprintf(stderr, "[smplx timing] submitter: %ld batches, %.1f states/batch; issuing %.3fs (pack + enqueue); GPU without a batch %.3fs; "
+                                 "issue-to-landing %.1f us on average; %.2f batches already in flight at issue\n",
+                         sweeps, sweeps ? (double)states / sweeps : 0.0, t_issue, t_gpu_idle, sweeps ? 1e6 * lat_sum / sweeps : 0.0,
+                         sweeps ? (double)depth_sum / sweeps : 0.0);
         return SMPLX_OK;
     };
 
