@@ -205,7 +205,9 @@ struct smplx_space {
     int32_t* d_queue[2] = {nullptr, nullptr};   // brick lists of the two passes in flight (level mode: the two frontier queues)
     int32_t* d_counts = nullptr;
     unsigned char* d_brick_flags = nullptr;     // brick mode: bricks whose halo changed in the current pass
+    int32_t* d_brick_queued = nullptr;          // wave-per-brick mode: 2 x nbricks "queued for the next pass" words
     bool bfs_level_mode = false;                // SMPLX_BFS=levels: the level-synchronous kernel of round 1 (A/B runs)
+    bool bfs_block_mode = false;       // SMPLX_BFS=blocks: the block-per-brick sweep kernel instead of the wave-per-brick one
     int bfs_bricks[3] = {0, 0, 0};
     int32_t* d_minus_one = nullptr;   // a device int holding -1 (k_expand: deferred pass without a counter)
     int64_t bfs_total = 0;
@@ -422,14 +424,28 @@ int run_bfs(smplx_space* s, const double xyz[3])
         HIP_TRY(hipGetLastError());
         const int grid = std::min(nbricks, 4096);
         int pass = 0;
-        std::vector<int32_t> cnt(2 * kShards * 32);
-        const int chunk = 16;
+        std::vector<int32_t> cnt(3 * kShards * 32);
+        // wave mode: three counter sets rotate (in, next, zeroed for the pass after), two "queued" arrays alternate
+        int32_t* queued[2] = {s->d_brick_queued, s->d_brick_queued + nbricks};
+        // passes are enqueued in chunks with one look at the counters per chunk: 16 while the front is wide, 4 once fewer
+        // than 256 bricks are flagged (the tail of a BFS is a handful of bricks per pass: a look costs about two empty
+        // passes, a chunk of 16 wasted eight of them on average)
+        int chunk = 16;
         while (true) {
             for (int k = 0; k < chunk; ++k, ++pass) {
                 const int in = pass & 1, out = (pass + 1) & 1;
-                hipLaunchKernelGGL(k_bfs_brick, dim3(grid), dim3(512), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
-                                   lists + in * list_ints, s->d_counts + in * kShards * 32, s->d_counts + out * kShards * 32, nbricks,
-                                   s->d_brick_flags);
+                if (s->bfs_block_mode)   // SMPLX_BFS=blocks: one 512-thread block per brick (kept for A/B runs)
+                    hipLaunchKernelGGL(k_bfs_brick, dim3(grid), dim3(512), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
+                                       lists + in * list_ints, s->d_counts + in * kShards * 32, s->d_counts + out * kShards * 32, nbricks,
+                                       s->d_brick_flags);
+                else {                   // one wave per brick; the pass appends to the next list itself
+                    const int c_in = pass % 3, c_next = (pass + 1) % 3, c_after = (pass + 2) % 3;
+                    hipLaunchKernelGGL(k_bfs_brick_wave, dim3(std::min(nbricks, 16384)), dim3(64), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
+                                       lists + in * list_ints, s->d_counts + c_in * kShards * 32, lists + out * list_ints,
+                                       s->d_counts + c_next * kShards * 32, s->d_counts + c_after * kShards * 32, nbricks,
+                                       queued[in], queued[out]);
+                    continue;
+                }
                 hipLaunchKernelGGL(k_bfs_compact, dim3(blocks_for(nbricks, 256)), dim3(256), 0, s->stream, s->d_brick_flags, nbricks,
                                    lists + out * list_ints, s->d_counts + out * kShards * 32, nbricks);
             }
@@ -437,8 +453,10 @@ int run_bfs(smplx_space* s, const double xyz[3])
             HIP_TRY(hipMemcpyAsync(cnt.data(), s->d_counts, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
             long pending = 0;
-            for (int k = 0; k < kShards; ++k) pending += cnt[(size_t)(pass & 1) * kShards * 32 + 32 * k];
+            const int set = s->bfs_block_mode ? (pass & 1) : pass % 3;   // the "in" counters of the pass that would come next
+            for (int k = 0; k < kShards; ++k) pending += cnt[(size_t)set * kShards * 32 + 32 * k];
             if (pending == 0) break;
+            chunk = pending < 256 ? 4 : 16;
             if (pass > 64 * (nbx + nby + nbz) + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
         }
         s->bfs_levels = pass;
@@ -1485,6 +1503,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     {
         const char* env = getenv("SMPLX_BFS");
         s->bfs_level_mode = env && std::strcmp(env, "levels") == 0;
+        s->bfs_block_mode = env && std::strcmp(env, "blocks") == 0;
     }
     for (int a = 0; a < 3; ++a) s->bfs_bricks[a] = (grid->n[a] + 7) / 8;
     const size_t nbricks = (size_t)s->bfs_bricks[0] * s->bfs_bricks[1] * s->bfs_bricks[2];
@@ -1492,6 +1511,8 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if ((e = hipMalloc((void**)&s->d_bfs, sizeof(int32_t) * s->bfs_total)) != hipSuccess) return bail(e, "hipMalloc bfs");
     if ((e = hipMalloc((void**)&s->d_brick_flags, nbricks + 64)) != hipSuccess) return bail(e, "hipMalloc bfs flags");
     if ((e = hipMemset(s->d_brick_flags, 0, nbricks + 64)) != hipSuccess) return bail(e, "hipMemset bfs flags");
+    if ((e = hipMalloc((void**)&s->d_brick_queued, sizeof(int32_t) * 2 * nbricks + 64)) != hipSuccess) return bail(e, "hipMalloc bfs queued");
+    if ((e = hipMemset(s->d_brick_queued, 0, sizeof(int32_t) * 2 * nbricks + 64)) != hipSuccess) return bail(e, "hipMemset bfs queued");
     if ((e = hipMalloc((void**)&s->d_queue[0], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
     if ((e = hipMalloc((void**)&s->d_queue[1], sizeof(int32_t) * (s->bfs_level_mode ? qn : 64))) != hipSuccess) return bail(e, "hipMalloc bfs queue");
     if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * (3 * 16 * 32 + 4))) != hipSuccess) return bail(e, "hipMalloc bfs counts");
@@ -1531,6 +1552,7 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_queue[1]) (void)hipFree(s->d_queue[1]);
     if (s->d_counts) (void)hipFree(s->d_counts);
     if (s->d_brick_flags) (void)hipFree(s->d_brick_flags);
+    if (s->d_brick_queued) (void)hipFree(s->d_brick_queued);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->d_table) (void)hipFree(s->d_table);
     if (s->small_trace) (void)hipHostFree(s->small_trace);

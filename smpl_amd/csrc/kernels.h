@@ -71,6 +71,9 @@ __global__ void k_bfs_seed(int* dist, int origin, int* queue, int* counts);
 __global__ void k_bfs_level(int* dist, const int* q_in, int* q_out, int* counts, int level, int dim_x, int dim_xy);
 __global__ void k_bfs_brick(int* dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz, const int* list_in,
                             const int* counts_in, int* counts_next, int shard_cap, unsigned char* flags);
+__global__ void k_bfs_brick_wave(int* dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz, const int* list_in,
+                                 const int* counts_in, int* list_next, int* counts_next, int* counts_after, int shard_cap,
+                                 int* queued_mine, int* queued_next);
 __global__ void k_bfs_compact(unsigned char* flags, int nbricks, int* list_out, int* counts_out, int shard_cap);
 __global__ void k_bfs_brick_seed(int* dist, size_t origin, int brick, int* list0, int* counts);
 }

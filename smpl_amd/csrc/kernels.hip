@@ -2328,12 +2328,171 @@ k_bfs_level(int* __restrict__ dist, const int* __restrict__ q_in, int* __restric
 // their counters on separate 128-byte lines (counts[32 k]): same-address atomics serialise at ~12 ns on this chip.
 #define SMPLX_BFS_SHARDS 16
 
+// One WAVE per brick (block = 64 lanes): lane (x, y) keeps its z-column of 8 cells in registers.  Against the block-per-
+// brick kernel below: no block barriers (a barrier of a one-wave block costs nothing), eight times as many bricks
+// resident per CU, and a change travels the whole column within one sweep (the z direction is relaxed in place, up
+// and down), so a brick needs a third of the sweeps.  In-plane neighbours come from the LDS tile, which the lanes
+// refresh with their columns at the start of every sweep; the halo (neighbour bricks' cells) is read once and never
+// changes during the sweeps.  Same fixed point as every label-correcting order: the BFS distances.
+extern "C" __global__ void __launch_bounds__(64)
+k_bfs_brick_wave(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz,
+                 const int* __restrict__ list_in, const int* __restrict__ counts_in, int* __restrict__ list_next,
+                 int* __restrict__ counts_next, int* __restrict__ counts_after, int shard_cap,
+                 int* __restrict__ queued_mine, int* __restrict__ queued_next)
+{
+    // The pass builds the next pass's brick list itself: a neighbour brick is claimed with an atomic exchange on its
+    // "queued for the next pass" word and appended by the claimer (no flag sweep, no compaction kernel: 40 launches
+    // fewer per BFS at 256^3).  Two queued-arrays alternate: a brick clears its own word of the array it was queued in,
+    // so that array is clean again when it next serves as "next".  Three counter sets rotate (in / next / the one
+    // zeroed for the pass after).
+    constexpr int TL = SMPLX_BRICK_TILE, TP = SMPLX_BRICK_TILE * SMPLX_BRICK_TILE;
+    __shared__ unsigned int tile[TL * TL * TL];
+    int pre[SMPLX_BFS_SHARDS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < SMPLX_BFS_SHARDS; ++k) pre[k + 1] = pre[k] + counts_in[32 * k];
+    const int n = pre[SMPLX_BFS_SHARDS];
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0 && t < SMPLX_BFS_SHARDS) counts_after[32 * t] = 0;
+    const int tx = t & 7, ty = t >> 3;
+    const size_t dim_xy = (size_t)dim_x * dim_y;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        int sh = 0;
+#pragma unroll
+        for (int k = 1; k < SMPLX_BFS_SHARDS; ++k) sh += it >= pre[k] ? 1 : 0;
+        const int b = list_in[(size_t)sh * shard_cap + (it - pre[sh])];
+        const int bxx = b % nbx, byy = (b / nbx) % nby, bzz = b / (nbx * nby);
+        const int ox = bxx * SMPLX_BRICK, oy = byy * SMPLX_BRICK, oz = bzz * SMPLX_BRICK;
+        if (t == 0) queued_mine[b] = 0;
+        {
+            // 1000 cells by 64 lanes: all 16 loads of a lane in flight before the first store (a rolled loop would put 16
+            // memory round trips end to end: that alone was 15 of the 25 us a lone brick took)
+            constexpr int NL = (TL * TL * TL + 63) / 64;
+            int raw[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int i = t + 64 * k;
+                const int lx = i % TL, ly = (i / TL) % TL, lz = i / TP;
+                const int px = ox + lx, py = oy + ly, pz = oz + lz;
+                raw[k] = 0x7FFFFFFF;
+                if (i < TL * TL * TL && px < dim_x && py < dim_y && pz < dim_z) raw[k] = dist[(size_t)pz * dim_xy + (size_t)py * dim_x + px];
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int i = t + 64 * k;
+                if (i < TL * TL * TL)
+                    tile[i] = raw[k] == -1 ? SMPLX_BFS_INF : (raw[k] == 0x7FFFFFFF ? SMPLX_BFS_WALLV : (unsigned int)raw[k]);
+            }
+        }
+        __syncthreads();
+        const int col = (ty + 1) * TL + (tx + 1);   // this lane's column in a tile plane
+        unsigned int v[SMPLX_BRICK], before[SMPLX_BRICK];
+#pragma unroll
+        for (int z = 0; z < SMPLX_BRICK; ++z) { v[z] = tile[(z + 1) * TP + col]; before[z] = v[z]; }
+        // in-plane 3x3 minima of the two halo planes: constant
+        unsigned int p_lo = SMPLX_BFS_WALLV, p_hi = SMPLX_BFS_WALLV;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const unsigned int a = tile[col + dy * TL + dx], c = tile[(TL - 1) * TP + col + dy * TL + dx];
+                p_lo = a < p_lo ? a : p_lo;
+                p_hi = c < p_hi ? c : p_hi;
+            }
+        // (the in-plane neighbours by wave shuffles instead of the LDS tile -- x: one lane, y: eight lanes, halo values
+        // in registers, no LDS traffic or barrier in the loop -- was built and measured: 32 ds_bpermute per sweep are
+        // slower than 64 plain LDS reads, 1.69 vs 1.58 ms at 256^3)
+        while (true) {
+            // the in-plane minimum of every level of the column (own cell included), from the tile as the lanes left it
+            unsigned int pm[SMPLX_BRICK];
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z) {
+                unsigned int m = v[z];
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dx == 0 && dy == 0) continue;
+                        const unsigned int nv = tile[(z + 1) * TP + col + dy * TL + dx];
+                        m = nv < m ? nv : m;   // walls (0xFFFFFFFF) and undiscovered cells never win
+                    }
+                pm[z] = m;
+            }
+            // relax the column in place, upwards then downwards: a cell takes 1 + the least of the three plane minima
+            bool changed = false;
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z) {
+                if (v[z] == SMPLX_BFS_WALLV) continue;
+                const unsigned int lo = z == 0 ? p_lo : pm[z - 1], hi = z == SMPLX_BRICK - 1 ? p_hi : pm[z + 1];
+                unsigned int m = lo < hi ? lo : hi;
+                m = pm[z] < m ? pm[z] : m;
+                if (m < SMPLX_BFS_INF && m + 1 < v[z]) { v[z] = m + 1; pm[z] = v[z] < pm[z] ? v[z] : pm[z]; changed = true; }
+            }
+#pragma unroll
+            for (int z = SMPLX_BRICK - 2; z >= 0; --z) {
+                if (v[z] == SMPLX_BFS_WALLV) continue;
+                const unsigned int hi = pm[z + 1];
+                if (hi < SMPLX_BFS_INF && hi + 1 < v[z]) { v[z] = hi + 1; pm[z] = v[z] < pm[z] ? v[z] : pm[z]; changed = true; }
+            }
+            if (!__syncthreads_or(changed ? 1 : 0)) break;   // one-wave block: the barrier only orders the LDS traffic
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z) tile[(z + 1) * TP + col] = v[z];
+            __syncthreads();
+        }
+        // write back what improved; the neighbour bricks that see an improved cell in their halo are flagged once per
+        // DIRECTION (a 27-bit mask per lane, OR-ed across the wave, one store per set bit) instead of once per cell
+        unsigned int xy = 0;   // (dy + 1) * 3 + (dx + 1) of the in-plane directions this lane's column borders on
+        {
+            const int sx0 = tx == 0 ? -1 : 0, sx1 = tx == SMPLX_BRICK - 1 ? 1 : 0;
+            const int sy0 = ty == 0 ? -1 : 0, sy1 = ty == SMPLX_BRICK - 1 ? 1 : 0;
+            for (int dy = sy0; dy <= sy1; ++dy)
+                for (int dx = sx0; dx <= sx1; ++dx) xy |= 1u << ((dy + 1) * 3 + (dx + 1));
+        }
+        unsigned int mask = 0;
+#pragma unroll
+        for (int z = 0; z < SMPLX_BRICK; ++z) {
+            if (v[z] < before[z]) {
+                const int px = ox + tx + 1, py = oy + ty + 1, pz = oz + z + 1;
+                dist[(size_t)pz * dim_xy + (size_t)py * dim_x + px] = (int)v[z];
+                mask |= xy << 9;
+                if (z == 0) mask |= xy;
+                if (z == SMPLX_BRICK - 1) mask |= xy << 18;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mask |= (unsigned int)__shfl_xor((int)mask, off);
+        int claimed = -1;
+        if (t < 27 && t != 13 && ((mask >> t) & 1u)) {
+            const int qx = bxx + t % 3 - 1, qy = byy + (t / 3) % 3 - 1, qz = bzz + t / 9 - 1;
+            if (!(qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz)) {
+                const int q = (qz * nby + qy) * nbx + qx;
+                if (atomicExch(&queued_next[q], 1) == 0) claimed = q;
+            }
+        }
+        const unsigned long long cm = __ballot(claimed >= 0);
+        if (cm != 0) {
+            const int shard = (int)(blockIdx.x % SMPLX_BFS_SHARDS);
+            int base = 0;
+            if (t == 0) base = atomicAdd(&counts_next[32 * shard], __popcll(cm));
+            base = __shfl(base, 0);
+            if (claimed >= 0) {
+                const int pos = base + __popcll(cm & ((1ull << t) - 1ull));
+                if (pos < shard_cap) list_next[(size_t)shard * shard_cap + pos] = claimed;
+            }
+        }
+        __syncthreads();   // the tile is reused by the block's next brick
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(512)
 k_bfs_brick(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz,
             const int* __restrict__ list_in, const int* __restrict__ counts_in, int* __restrict__ counts_next, int shard_cap,
             unsigned char* __restrict__ flags)
 {
     __shared__ unsigned int tile[SMPLX_BRICK_TILE * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE];
+    // minimum over the 3x3 in-plane neighbourhood (centre included) of every interior (x, y), per tile plane: the 26
+    // neighbours of a cell are three such minima -- 8 + 2 LDS reads per cell and sweep instead of 26
+    __shared__ unsigned int plane[SMPLX_BRICK_TILE][SMPLX_BRICK][SMPLX_BRICK];
     int pre[SMPLX_BFS_SHARDS + 1];
     pre[0] = 0;
 #pragma unroll
@@ -2366,21 +2525,39 @@ k_bfs_brick(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nbx, in
         const int me = (tz + 1) * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE + (ty + 1) * SMPLX_BRICK_TILE + (tx + 1);
         const unsigned int before = tile[me];
         unsigned int v = before;
+        // the two halo planes (z = -1 and z = 8 of the brick) never change during the sweeps: their in-plane minima once
+        if (tz == 0 || tz == SMPLX_BRICK - 1) {
+            const int lz = tz == 0 ? 0 : SMPLX_BRICK_TILE - 1;
+            const int c = lz * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE + (ty + 1) * SMPLX_BRICK_TILE + (tx + 1);
+            unsigned int m = SMPLX_BFS_WALLV;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const unsigned int nv = tile[c + dy * SMPLX_BRICK_TILE + dx];
+                    m = nv < m ? nv : m;
+                }
+            plane[lz][ty][tx] = m;
+        }
         int changed;
         do {
             changed = 0;
+            // in-plane minimum of this cell's own plane (the cell itself included: it can never improve on itself)
+            unsigned int p = v;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    const unsigned int nv = tile[me + dy * SMPLX_BRICK_TILE + dx];
+                    p = nv < p ? nv : p;     // walls (0xFFFFFFFF) and undiscovered cells never win
+                }
+            plane[tz + 1][ty][tx] = p;
+            __syncthreads();
             if (v != SMPLX_BFS_WALLV) {
-                unsigned int m = SMPLX_BFS_INF;
-#pragma unroll
-                for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            if (dx == 0 && dy == 0 && dz == 0) continue;
-                            const unsigned int nv = tile[me + dz * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE + dy * SMPLX_BRICK_TILE + dx];
-                            m = nv < m ? nv : m;     // walls (0xFFFFFFFF) and undiscovered cells never win
-                        }
+                const unsigned int a = plane[tz][ty][tx], b = plane[tz + 2][ty][tx];
+                unsigned int m = a < b ? a : b;
+                m = p < m ? p : m;
                 if (m < SMPLX_BFS_INF && m + 1 < v) { v = m + 1; tile[me] = v; changed = 1; }
             }
         } while (__syncthreads_or(changed));
