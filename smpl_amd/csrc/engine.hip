@@ -427,6 +427,8 @@ int run_bfs(smplx_space* s, const double xyz[3])
         std::vector<int32_t> cnt(3 * kShards * 32);
         // wave mode: three counter sets rotate (in, next, zeroed for the pass after), two "queued" arrays alternate
         int32_t* queued[2] = {s->d_brick_queued, s->d_brick_queued + nbricks};
+        int wave_grid = 16384;
+        if (const char* e = getenv("SMPLX_BFS_GRID")) wave_grid = std::max(64, atoi(e));
         // passes are enqueued in chunks with one look at the counters per chunk: 16 while the front is wide, 4 once fewer
         // than 256 bricks are flagged (the tail of a BFS is a handful of bricks per pass: a look costs about two empty
         // passes, a chunk of 16 wasted eight of them on average)
@@ -440,7 +442,7 @@ int run_bfs(smplx_space* s, const double xyz[3])
                                        s->d_brick_flags);
                 else {                   // one wave per brick; the pass appends to the next list itself
                     const int c_in = pass % 3, c_next = (pass + 1) % 3, c_after = (pass + 2) % 3;
-                    hipLaunchKernelGGL(k_bfs_brick_wave, dim3(std::min(nbricks, 16384)), dim3(64), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
+                    hipLaunchKernelGGL(k_bfs_brick_wave, dim3(std::min(nbricks, wave_grid)), dim3(64), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
                                        lists + in * list_ints, s->d_counts + c_in * kShards * 32, lists + out * list_ints,
                                        s->d_counts + c_next * kShards * 32, s->d_counts + c_after * kShards * 32, nbricks,
                                        queued[in], queued[out]);
