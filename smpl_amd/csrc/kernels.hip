@@ -342,48 +342,6 @@ __device__ __forceinline__ void fk_two_links(const ModelLds* __restrict__ M, con
     }
 }
 
-// sphere tree vs sphere tree (self_collision_model.cpp:1093-1218); false = collision
-__device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
-                                             int ta, int tb)
-{
-    double Ta[12], Tb[12];
-    fk_two_links(M, L, e, M->tree_joint[ta], M->tree_joint[tb], Ta, Tb);
-    int sp = 0;
-    int na = M->tree_first[ta + 1] - 1, nb = M->tree_first[tb + 1] - 1;
-    while (true) {
-        const LDS_AS SmplxNode& A = L.nodes[na];
-        const LDS_AS SmplxNode& B = L.nodes[nb];
-        double ca[3] = {A.c[0], A.c[1], A.c[2]}, cb[3] = {B.c[0], B.c[1], B.c[2]};
-        double pa[3], pb[3];
-        xform(Ta, ca, pa);
-        xform(Tb, cb, pb);
-        const double dx = pb[0] - pa[0], dy = pb[1] - pa[1], dz = pb[2] - pa[2];
-        const double cd2 = (dx * dx + dy * dy) + dz * dz;
-        const double rr = A.r + B.r;
-        if (!(cd2 > rr * rr)) {
-            const bool la = A.left < 0, lb = B.left < 0;
-            if (la && lb) return false;   // leaf x leaf: the ACM lookup by sphere name never matches (:1136)
-            bool split_a;
-            if (la) split_a = false;
-            else if (lb) split_a = true;
-            else split_a = A.r > B.r;
-            // both children are visited unless pruned; visiting order does not change the boolean
-            if (split_a) {
-                lds_b(L, sp++) = (unsigned char)A.right; lds_b(L, sp++) = (unsigned char)nb;
-                na = A.left;
-            } else {
-                lds_b(L, sp++) = (unsigned char)na; lds_b(L, sp++) = (unsigned char)B.right;
-                nb = B.left;
-            }
-            continue;
-        }
-        if (sp == 0) break;
-        nb = lds_b(L, --sp);
-        na = lds_b(L, --sp);
-    }
-    return true;
-}
-
 // the part of a joint record the chain step needs, in registers
 struct JointHead {
     int kind, var, src, save_slot, tree;
@@ -714,6 +672,98 @@ __device__ __forceinline__ void const_planning_chain(const ModelLds* __restrict_
     }
 }
 #endif   // SMPLX_CONST_MODEL
+
+#ifdef SMPLX_CONST_MODEL
+// fk_two_links for the per-robot build: the transforms of the links at joints ja and jb, the chain walked as in
+// const_chain (same operations in the same order: identical bits), stopping behind the later of the two
+template <int J>
+__device__ __forceinline__ void const_two_links(const ModelLds* __restrict__ M, const ThreadLds& L, double T[12], const double* q,
+                                                int ja, int jb, int last, double Ta[12], double Tb[12])
+{
+    if constexpr (J < CM_NJ) {
+        if (J > last) return;
+        constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J];
+        if constexpr (src >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * src + i);
+        }
+        double qv = 0.0;
+        if constexpr (var >= 0) qv = q[var];
+        if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J, src == SMPLX_SRC_ROOT>(qv, T);
+        else apply_joint(&M->joints[J], qv, T, src == SMPLX_SRC_ROOT);
+        if constexpr (save >= 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = T[i];
+        }
+        if (J == ja) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Ta[i] = T[i];
+        }
+        if (J == jb) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Tb[i] = T[i];
+        }
+        const_two_links<J + 1>(M, L, T, q, ja, jb, last, Ta, Tb);
+    }
+}
+#endif
+
+// sphere tree vs sphere tree (self_collision_model.cpp:1093-1218); false = collision
+__device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
+                                             int ta, int tb)
+{
+    double Ta[12], Tb[12];
+#ifdef SMPLX_CONST_MODEL
+    {
+        // per-robot build: the chain as straight-line code (the generic loop reads every joint record from LDS and
+        // dispatches on its kind: under random configurations, where root spheres of checked pairs overlap in most
+        // waves, it was 78 % of the K2 micro-benchmark)
+        double T[12], q[CM_NV];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { T[i] = 0.0; Ta[i] = 0.0; Tb[i] = 0.0; }
+#pragma unroll
+        for (int v = 0; v < CM_NV; ++v) q[v] = lds_d(L, L.q_base + v);
+        const int ja = M->tree_joint[ta], jb = M->tree_joint[tb];
+        const_two_links<0>(M, L, T, q, ja, jb, ja > jb ? ja : jb, Ta, Tb);
+    }
+#else
+    fk_two_links(M, L, e, M->tree_joint[ta], M->tree_joint[tb], Ta, Tb);
+#endif
+    int sp = 0;
+    int na = M->tree_first[ta + 1] - 1, nb = M->tree_first[tb + 1] - 1;
+    while (true) {
+        const LDS_AS SmplxNode& A = L.nodes[na];
+        const LDS_AS SmplxNode& B = L.nodes[nb];
+        double ca[3] = {A.c[0], A.c[1], A.c[2]}, cb[3] = {B.c[0], B.c[1], B.c[2]};
+        double pa[3], pb[3];
+        xform(Ta, ca, pa);
+        xform(Tb, cb, pb);
+        const double dx = pb[0] - pa[0], dy = pb[1] - pa[1], dz = pb[2] - pa[2];
+        const double cd2 = (dx * dx + dy * dy) + dz * dz;
+        const double rr = A.r + B.r;
+        if (!(cd2 > rr * rr)) {
+            const bool la = A.left < 0, lb = B.left < 0;
+            if (la && lb) return false;   // leaf x leaf: the ACM lookup by sphere name never matches (:1136)
+            bool split_a;
+            if (la) split_a = false;
+            else if (lb) split_a = true;
+            else split_a = A.r > B.r;
+            // both children are visited unless pruned; visiting order does not change the boolean
+            if (split_a) {
+                lds_b(L, sp++) = (unsigned char)A.right; lds_b(L, sp++) = (unsigned char)nb;
+                na = A.left;
+            } else {
+                lds_b(L, sp++) = (unsigned char)na; lds_b(L, sp++) = (unsigned char)B.right;
+                nb = B.left;
+            }
+            continue;
+        }
+        if (sp == 0) break;
+        nb = lds_b(L, --sp);
+        na = lds_b(L, --sp);
+    }
+    return true;
+}
 
 // CollisionSpace::isStateValid for one configuration (collision_space.cpp:532-536 ->
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
