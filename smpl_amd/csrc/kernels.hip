@@ -342,6 +342,33 @@ __device__ __forceinline__ void fk_two_links(const ModelLds* __restrict__ M, con
     }
 }
 
+// Checked link pairs whose root spheres overlap and are not both leaves wait here for the sphere-tree pass behind the
+// chain: (earlier tree << 8 | later tree), 16 bits each, twelve of them in three words.  More than that -> every pair
+// is rechecked.  (Four slots overflowed in most waves of random configurations, and a recheck of every pair pays a
+// two-link FK per pair.)
+#define SMPLX_PENDING_MAX 12
+struct PendingPairs {
+    unsigned long long w0, w1, w2;
+    int n;
+};
+__device__ __forceinline__ bool pend_push(PendingPairs& P, int ta, int t)
+{
+    if (P.n >= SMPLX_PENDING_MAX) return false;
+    const unsigned long long c = (unsigned long long)((ta << 8) | t) << (16 * (P.n & 3));
+    const int k = P.n >> 2;
+    if (k == 0) P.w0 |= c;
+    else if (k == 1) P.w1 |= c;
+    else P.w2 |= c;
+    ++P.n;
+    return true;
+}
+__device__ __forceinline__ int pend_get(const PendingPairs& P, int i)
+{
+    const int k = i >> 2;
+    const unsigned long long w = k == 0 ? P.w0 : (k == 1 ? P.w1 : P.w2);
+    return (int)((w >> (16 * (i & 3))) & 0xFFFF);
+}
+
 // the part of a joint record the chain step needs, in registers
 struct JointHead {
     int kind, var, src, save_slot, tree;
@@ -371,8 +398,7 @@ struct ChainState {
     double q[CM_NV];
     double roots[3 * (CM_NT > 0 ? CM_NT : 1)];   // only the slots that lead a pair are ever touched
     bool pair_hit, recheck_all;
-    unsigned long long pending;
-    int npending;
+    PendingPairs P;
     // the tree whose root lookup is in flight (software pipelining, see const_chain): its link transform and the
     // squared cell distance the lookup returns
     double Tp[12];
@@ -398,12 +424,7 @@ __device__ __forceinline__ void const_pairs(const ThreadLds& L, ChainState& C, c
             if constexpr (CM_ROOT_LEAF[ta] && CM_ROOT_LEAF[T_]) {
                 C.pair_hit = true;
             } else {
-                if (C.npending < 4) {
-                    C.pending = (C.pending << 16) | (unsigned long long)((ta << 8) | T_);
-                    ++C.npending;
-                } else {
-                    C.recheck_all = true;
-                }
+                if (!pend_push(C.P, ta, T_)) C.recheck_all = true;
             }
         }
         const_pairs<T_, K + 1, KEND>(L, C, rp);
@@ -776,8 +797,8 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = 0.0;
     bool pair_hit = false, recheck_all = false;
-    unsigned long long pending = 0;   // queued (earlier tree, later tree) pairs, 16 bits each
-    int npending = 0;
+    PendingPairs P;   // queued (earlier tree, later tree) pairs
+    P.w0 = 0; P.w1 = 0; P.w2 = 0; P.n = 0;
 #ifdef ABL_NO_FK
     lookups += (int)e.alpha; return true;
 #endif
@@ -788,7 +809,7 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
         for (int i = 0; i < 12; ++i) C.T[i] = 0.0;
 #pragma unroll
         for (int v = 0; v < CM_NV; ++v) C.q[v] = lds_d(L, L.q_base + v);
-        C.pair_hit = false; C.recheck_all = false; C.pending = 0; C.npending = 0;
+        C.pair_hit = false; C.recheck_all = false; C.P = P;
         C.pd2 = 0;
 #if !defined(SMPLX_CHAIN_SWEEP) || defined(ABL_NO_TREES) || defined(ABL_NO_LOOKUP)   // measured: the sweep is SLOWER (27.2 vs 23.7 us), see its comment
         if (!const_chain<0, -1>(M, L, g, C, lookups)) return false;
@@ -803,11 +824,13 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
             // second walk, with the descents (the pair bookkeeping is redone from scratch: same inputs, same outcome)
 #pragma unroll
             for (int i = 0; i < 12; ++i) C.T[i] = 0.0;
-            C.pair_hit = false; C.recheck_all = false; C.pending = 0; C.npending = 0;
+            C.pair_hit = false; C.recheck_all = false; C.P = P;
             if (!const_chain<0, -1, true>(M, L, g, C, lookups)) return false;
         }
 #endif
-        pair_hit = C.pair_hit; recheck_all = C.recheck_all; pending = C.pending; npending = C.npending;
+        pair_hit = C.pair_hit; recheck_all = C.recheck_all;
+        const PendingPairs filled = C.P;
+        P = filled;
     }
     const int nj = 0;
 #else
@@ -870,18 +893,13 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
                 if (cd2 > rr * rr) continue;
                 if (A.left < 0 && B.left < 0) { pair_hit = true; continue; }
                 // queue (ta, t): 8 bits each, up to 4 pairs in the 64-bit word; more -> recheck everything
-                if (npending < 4) {
-                    pending = (pending << 16) | (unsigned long long)((ta << 8) | t);
-                    ++npending;
-                } else {
-                    recheck_all = true;
-                }
+                if (!pend_push(P, ta, t)) recheck_all = true;
             }
         }
     }
     // unresolved pairs (normally none): one call site for the slow path, so it can be inlined without
     // putting the model view into scratch memory
-    const int total = recheck_all ? M->pair_first[M->ntrees] : npending;
+    const int total = recheck_all ? M->pair_first[M->ntrees] : P.n;
     int tcur = 0;
     for (int i = 0; i < total && !pair_hit; ++i) {
         int ta, t;
@@ -890,7 +908,7 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
             t = tcur;
             ta = M->pair_other[i];
         } else {
-            const int code = (int)((pending >> (16 * i)) & 0xFFFF);
+            const int code = pend_get(P, i);
             ta = code >> 8;
             t = code & 0xFF;
         }
