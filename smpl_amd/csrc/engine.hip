@@ -1123,8 +1123,9 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
     const int M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
-    if (src == s && s->inflight_small && s->adaptive_small) {
-        // issue-to-landing time of the single-launch path (the search thread has been polling since the issue)
+    if (src == s && s->inflight_small && s->adaptive_small && B <= 16) {
+        // issue-to-landing time of the single-launch path (the search thread has been polling since the issue); only the
+        // handful-of-states batches are watched: a batch of hundreds of states legitimately takes longer
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_issue).count();
         s->small_latency = s->small_seen == 0 ? dt : 0.8 * s->small_latency + 0.2 * dt;
         // (every rollout level is one more launch in the batch: 15 us of allowance each)
