@@ -376,6 +376,32 @@ def config3(n: int = 150, nclutter: int = 20, seed: int = 3) -> Config:
                   [3.0 * DEG] * 7, boxes)
 
 
+PR2_RIGHT_ARM_JOINTS = ["r_shoulder_pan_joint", "r_shoulder_lift_joint", "r_upper_arm_roll_joint", "r_elbow_flex_joint",
+                        "r_forearm_roll_joint", "r_wrist_flex_joint", "r_wrist_roll_joint"]   # smpl_test/launch/goal_pr2.launch:16-23
+
+
+def pr2_right_arm_text(collision_yaml: str, urdf_xml: str, allowed_pairs=()) -> str:
+    """SURVEY 8d cfg 3, "PR2 right arm as data": the plain-text model built from the reference's own collision-model file
+    (sbpl_collision_checking_test/config/collision_model_pr2.yaml: 23 leaf spheres on 8 links of group `right_arm`,
+    chains and nested groups resolved as robot_collision_model.cpp:517-623 does) and a URDF subset holding the arm's
+    kinematics (the reference tree has no PR2 URDF: goal_pr2.launch takes it from pr2_description).  Planning joints and
+    planning link as goal_pr2.launch:14-29; `allowed_pairs`: link pairs never checked against each other (the right-arm rows
+    of the demo's allowed-collision matrix, call_planner.cpp:441-1526)."""
+    from . import formats
+    links = formats.group_links_from_collision_yaml(collision_yaml, "right_arm", urdf_xml)
+    spheres = formats.sphere_lines_from_collision_yaml(collision_yaml, links=links)
+    return formats.urdf_to_robot_text(urdf_xml, "right_arm", links, PR2_RIGHT_ARM_JOINTS, "r_gripper_palm_link", spheres,
+                                      [tuple(p) for p in allowed_pairs])
+
+
+def config3_pr2(collision_yaml: str, urdf_xml: str, allowed_pairs=(), n: int = 150) -> Config:
+    """cfg 3 with the PR2 right arm built from data files (pr2_right_arm_text) in the cfg-3 scene."""
+    import dataclasses
+    base = config3(n)
+    goal = [ARM7_START[i] + c * DEG for i, c in enumerate([-49, 7, 21, -14, -8, -12, 16])]
+    return dataclasses.replace(base, name="cfg3_pr2", robot_text=pr2_right_arm_text(collision_yaml, urdf_xml, allowed_pairs), goal=goal)
+
+
 def config_small(n: int = 64, seed: int = 7, nboxes: int = 6) -> Config:
     """Small test scene (64^3 @ 0.04 m): the oracle finishes a full ARA* query in well under a second."""
     res = 0.04

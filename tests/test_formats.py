@@ -8,7 +8,7 @@ from oracle_binding import Oracle
 from smpl_amd import formats, scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-REF_YAML = "/root/reference/sbpl_collision_checking_test/config/collision_model_pr2.yaml"
+REF_YAML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collision_model_pr2.yaml")   # fixture copy of the reference's data file
 
 
 def test_env_file_of_the_reference_scene():
@@ -33,7 +33,6 @@ def test_reference_mprim_file_loads_as_upstream_rows(small_cfg):
     assert np.array_equal(a["flags"], b["flags"]) and np.array_equal(a["q"], b["q"])
 
 
-@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="the reference tree is only present in the build container")
 def test_sphere_lines_from_the_reference_collision_yaml():
     lines = formats.sphere_lines_from_collision_yaml(open(REF_YAML).read(), links=["r_upper_arm_roll_link", "r_shoulder_pan_link"],
                                                      rename={"r_upper_arm_roll_link": "upper_arm_link"})
@@ -82,7 +81,6 @@ def test_urdf_subset_reader_produces_a_model_the_host_compiler_accepts():
                                    "arm", ["l1"], ["j1"], "l1")
 
 
-@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="the reference tree is only present in the build container")
 def test_group_links_from_the_reference_collision_yaml():
     links = formats.group_links_from_collision_yaml(open(REF_YAML).read(), "right_gripper")
     assert links == ["r_gripper_palm_link", "r_gripper_r_finger_link", "r_gripper_r_finger_tip_link", "r_gripper_l_finger_link",
@@ -108,3 +106,25 @@ robot_collision_model:
     assert formats.group_links_from_collision_yaml(y, "arm", ARM_URDF) == ["tool", "l1", "l2", "l3"]
     with pytest.raises(ValueError):
         formats.group_links_from_collision_yaml(y.replace("base: l1", "base: head"), "arm", ARM_URDF)
+
+
+def test_pr2_right_arm_as_data_compiles_to_the_surveyed_model(cfg3_pr2):
+    """cfg 3's robot from data files: 7 planning variables, 8 sphere trees with 1, 4, 7, 3, 2, 2, 2, 2 leaves (23 leaves:
+    SURVEY section 2, K2 row), the limits of the URDF subset, and only the five link pairs the demo's allowed-collision
+    matrix leaves checked (r_shoulder_pan_link against the wrist-roll link, the fingers and the finger tips)."""
+    from smpl_amd import capi
+    text = cfg3_pr2.robot_text
+    lines = text.splitlines()
+    spheres = [l.split() for l in lines if l.startswith("sphere ")]
+    per_link = {}
+    for sp in spheres:
+        per_link[sp[1]] = per_link.get(sp[1], 0) + 1
+    assert len(spheres) == 23 and sorted(per_link.values()) == [1, 2, 2, 2, 2, 3, 4, 7]
+    assert per_link["r_forearm_roll_link"] == 7 and per_link["r_upper_arm_roll_link"] == 4 and per_link["r_shoulder_pan_link"] == 1
+    assert any(l.startswith("joint r_elbow_flex_joint revolute r_upper_arm_link r_elbow_flex_link  0.4 0.0 0.0") and l.endswith("-2.1213 -0.15")
+               for l in lines)
+    assert any(l.startswith("joint r_forearm_roll_joint continuous") for l in lines)
+    assert sum(l.startswith("acm ") for l in lines) == 83
+    m = capi.Model(text)
+    assert (m.nvars, m.ntrees) == (7, 8)
+    assert m.npairs == 5

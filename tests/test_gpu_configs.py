@@ -380,3 +380,34 @@ def test_root_lookup_sweep_build_gives_the_same_results(small_cfg, monkeypatch):
     Q = scenes.random_states(scenes.ARM7_LIMITS, 96, 5)
     o.set_order(chain=True)
     _compare_batch(o, s, Q)
+
+
+PR2_RIGHT_ARM_LIMITS = [(-2.1353981634, 0.564601836603), (-0.3536, 1.2963), (-3.75, 0.65), (-2.1213, -0.15),
+                        (-np.pi, np.pi), (-2.0, -0.1), (-np.pi, np.pi)]
+
+
+def test_config3_pr2_right_arm_as_data(cfg3_pr2):
+    """SURVEY cfg 3 as specified: the PR2 right arm from data files (the reference's collision_model_pr2.yaml, a URDF
+    subset of the arm, the right-arm rows of the demo's allowed-collision matrix) in the 150^3 cluttered-tabletop scene,
+    eps 100.  BFS grid, an expansion batch (start + random states within the PR2's limits), random state validity and the
+    bounded search against the oracle fed the same model text."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = cfg3_pr2
+    o = Oracle(cfg)
+    s = capi.Space.from_config(cfg, batch_states=1024)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert np.array_equal(o.goal_pose(), s.goal_pose())
+    assert np.array_equal(o.bfs_grid(), s.bfs_grid())
+    Q = np.vstack([np.array(cfg.start), scenes.random_states(PR2_RIGHT_ARM_LIMITS, 95, 33)])
+    o.set_order(chain=True)
+    _compare_batch(o, s, Q)
+    R = scenes.random_states(PR2_RIGHT_ARM_LIMITS, 2000, 34)
+    ok, lk = s.state_valid_batch(R)
+    want = np.array([o.state_valid(q)[0] for q in R[:400]])
+    assert np.array_equal(ok[:400].astype(bool), want.astype(bool)) and 0.05 < ok.mean() < 0.95
+    o.set_order(chain=False)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start) == 1
+    eo, go = _same_search(o, s, 100.0, 2500, 2500)
+    assert go["solved"] == 1 and go["cost"] > 0
