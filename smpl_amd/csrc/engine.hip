@@ -311,6 +311,7 @@ struct smplx_space {
     std::vector<std::pair<uint64_t, int32_t>> pool;   // binary min-heap of (rank key, id) of unevaluated states
     // a frontier batch in flight (issued on `stream`, completion signalled by `batch_done`)
     std::vector<int32_t> inflight;
+    std::vector<double> inflight_q;     // smplx_plan_multi: the joint values of `inflight`, staged by the query's worker
     hipEvent_t batch_done = nullptr;
     bool inflight_zero_copy = false;   // the batch in flight wrote its results straight into the pinned host buffers
     // Small batches: the single-launch kernel costs the host one launch (27 us issue-to-landing for the handful of states
@@ -2562,6 +2563,12 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                 if (r == Search::R_YIELD) {
                     if (S[q].miss_id >= 0) {
                         select_batch(spaces[q], S[q].miss_id, cap_q);
+                        {   // stage the parents' joint values for the submitter
+                            smplx_space* sq = spaces[q];
+                            sq->inflight_q.resize(sq->inflight.size() * (size_t)N);
+                            size_t r = 0;
+                            for (int32_t id : sq->inflight) { std::memcpy(&sq->inflight_q[r * N], &sq->qs[(size_t)id * N], sizeof(double) * N); ++r; }
+                        }
                         qstate[q].store(QS_REQUESTED, std::memory_order_release);
                     }
                 } else {
@@ -2590,7 +2597,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         double t_issue = 0;
         int in_flight = 0, next_set = 0, oldest = 0;
         // SMPLX_DEBUG_TIMING: how long the GPU had nothing of this shard, issue-to-landing time, depth at issue
-        double t_gpu_idle = 0, lat_sum = 0;
+        double t_gpu_idle = 0, lat_sum = 0, t_pack = 0;
         long depth_sum = 0;
         auto idle_since = std::chrono::steady_clock::now();
         std::chrono::steady_clock::time_point issued_at[kSets];
@@ -2669,11 +2676,13 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     Nf.ins_items.clear();
                     for (int q : Nf.queries) {
                         smplx_space* sq = spaces[q];
-                        for (int32_t id : sq->inflight) {
-                            std::memcpy(&Nf.p_q.p[row * N], &sq->qs[(size_t)id * N], sizeof(double) * N);
-                            Nf.p_stateq.p[row] = (unsigned short)q;
-                            ++row;
-                        }
+                        // the parents' joint values were staged by the query's worker when it made the request (they were in
+                        // its cache then; gathering 270 rows from 58 queries' state arrays here cost the submitter ~20 us
+                        // of cache misses per batch)
+                        const size_t nrows = sq->inflight.size();
+                        std::memcpy(&Nf.p_q.p[row * N], sq->inflight_q.data(), sizeof(double) * N * nrows);
+                        for (size_t k = 0; k < nrows; ++k) Nf.p_stateq.p[row + k] = (unsigned short)q;
+                        row += nrows;
                         // a requesting query is not being touched by its worker: its committed states join the device table
                         if ((e = table_grow_if_needed(sq))) return e;
                         table_take_pending(sq, q, Nf.ins_items);
@@ -2688,7 +2697,11 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                             if ((e = Nf.p_q.reserve(need))) return e;
                             size_t r2 = 0;
                             for (int q : Nf.queries)
-                                for (int32_t id : spaces[q]->inflight) { std::memcpy(&Nf.p_q.p[r2 * N], &spaces[q]->qs[(size_t)id * N], sizeof(double) * N); ++r2; }
+                            {
+                                const size_t nrows = spaces[q]->inflight.size();
+                                std::memcpy(&Nf.p_q.p[r2 * N], spaces[q]->inflight_q.data(), sizeof(double) * N * nrows);
+                                r2 += nrows;
+                            }
                         }
                         if ((e = Nf.b_q.reserve(need))) return e;
                         k5.n_items = (int)(Nf.ins_items.size() / ((size_t)N + 2));
@@ -2701,6 +2714,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     // kernel then checked the snap-to-goal edge of every state ungated, see k_small_batch.)
                     if (B <= small_zero_copy_max && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
                         // one launch, no copies: parents, query indices and results live in pinned host memory
+                        if (dbg) t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
                         ZeroCopy zc;
                         zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h; zc.id = Nf.pv.id;
                         k5.items = (const int32_t*)(Nf.p_q.p + total * N);
@@ -2735,9 +2749,9 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         // drain what is still in flight (only on error paths: with no live query nothing is pending)
         for (BatchBuffers& Bf : sets) if (Bf.stream) (void)hipStreamSynchronize(Bf.stream);
         if (dbg) fprintf(stderr, "[smplx timing] submitter: %ld batches, %.1f states/batch; issuing %.3fs (pack + enqueue); GPU without a batch %.3fs; "
-                                 "issue-to-landing %.1f us on average; %.2f batches already in flight at issue\n",
+                                 "issue-to-landing %.1f us on average; %.2f batches already in flight at issue; of the issuing, %.3fs before the launch call\n",
                          sweeps, sweeps ? (double)states / sweeps : 0.0, t_issue, t_gpu_idle, sweeps ? 1e6 * lat_sum / sweeps : 0.0,
-                         sweeps ? (double)depth_sum / sweeps : 0.0);
+                         sweeps ? (double)depth_sum / sweeps : 0.0, t_pack);
         return SMPLX_OK;
     };
 
