@@ -428,8 +428,11 @@ int run_bfs(smplx_space* s, const double xyz[3])
         std::vector<int32_t> cnt(3 * kShards * 32);
         // wave mode: three counter sets rotate (in, next, zeroed for the pass after), two "queued" arrays alternate
         int32_t* queued[2] = {s->d_brick_queued, s->d_brick_queued + nbricks};
-        int wave_grid = 16384;
-        if (const char* e = getenv("SMPLX_BFS_GRID")) wave_grid = std::max(64, atoi(e));
+        // blocks per pass: every block of a launch reads the counters even when it has no brick, so a launch of 16 384
+        // mostly idle blocks costs ~5 us; in the tail (fewer than 256 bricks flagged) 2 048 do
+        int wave_grid_max = 16384;
+        if (const char* e = getenv("SMPLX_BFS_GRID")) wave_grid_max = std::max(64, atoi(e));
+        int wave_grid = wave_grid_max;   // (2 048 for the first chunk was tried: the front passes 2 048 bricks by pass 10 -- slower)
         // passes are enqueued in chunks with one look at the counters per chunk: 16 while the front is wide, 4 once fewer
         // than 256 bricks are flagged (the tail of a BFS is a handful of bricks per pass: a look costs about two empty
         // passes, a chunk of 16 wasted eight of them on average)
@@ -460,6 +463,7 @@ int run_bfs(smplx_space* s, const double xyz[3])
             for (int k = 0; k < kShards; ++k) pending += cnt[(size_t)set * kShards * 32 + 32 * k];
             if (pending == 0) break;
             chunk = pending < 256 ? 4 : 16;
+            wave_grid = pending < 256 ? std::min(wave_grid_max, 2048) : wave_grid_max;
             if (pass > 64 * (nbx + nby + nbz) + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
         }
         s->bfs_levels = pass;
