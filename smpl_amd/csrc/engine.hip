@@ -2515,12 +2515,17 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
     const bool small_device = getenv("SMPLX_MULTI_SMALL_DEVICE") != nullptr;   // A/B switch: single launch with device buffers + DMA
     smplx_space* lead = spaces[0];
     const int N = lead->N, M = lead->M;
-    std::vector<std::atomic<int>> qstate(nq);
+    // one cache line per query state and per counter: the submitter polls them while the workers write them (with the
+    // states packed 16 to a line, a scan of all queries cost the submitter 15-50 us per batch and slowed every worker store)
+    struct alignas(64) PaddedInt { std::atomic<int> v{0}; };
+    std::vector<PaddedInt> qstate_store(nq);
+    auto qstate = [&](int q) -> std::atomic<int>& { return qstate_store[q].v; };
+    PaddedInt pend_cnt[8], live_cnt[8];   // per issue group: requests waiting / queries not finished
     std::vector<long> row_of(nq, -1);
     std::vector<int> set_of(nq, -1);
     std::atomic<int> remaining{nq}, error{0};
     std::string error_msg;
-    for (int q = 0; q < nq; ++q) { qstate[q].store(QS_RUNNABLE); S[q].defer_issue = true; S[q].pause_after = 16; }
+    for (int q = 0; q < nq; ++q) { qstate(q).store(QS_RUNNABLE); S[q].defer_issue = true; S[q].pause_after = 16; }
     {
         std::vector<const SmplxSpaceDev*> tab(nq);
         for (int q = 0; q < nq; ++q) tab[q] = spaces[q]->d_space;
@@ -2534,6 +2539,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
     if (const char* e = getenv("SMPLX_ISSUE_PERCENT")) issue_percent = std::max(1, std::min(100, atoi(e)));
     int groups = 1;   // SMPLX_ISSUE_GROUPS: batches are formed within a group of queries (A/B switch, see the submitter)
     if (const char* e = getenv("SMPLX_ISSUE_GROUPS")) groups = std::max(1, std::min(8, atoi(e)));
+    for (int q = 0; q < nq; ++q) live_cnt[(q / nworkers) % groups].v.fetch_add(1, std::memory_order_relaxed);
     std::vector<BatchBuffers> sets(kSets);
 
     auto fail = [&](int code, const std::string& msg) {
@@ -2550,14 +2556,14 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
             bool progressed = false;
             for (int q = w; q < nq; q += nworkers) {
                 if (done[q]) continue;
-                int st = qstate[q].load(std::memory_order_acquire);
+                int st = qstate(q).load(std::memory_order_acquire);
                 if (st == QS_REQUESTED || st == QS_IN_FLIGHT) continue;
                 const auto a0 = std::chrono::steady_clock::now();
                 if (st == QS_LANDED) {
                     BatchBuffers& Bf = sets[set_of[q]];
                     if (int e = collect_batch(spaces[q], lead, (size_t)row_of[q], &Bf.pv)) { fail(e, g_error); return; }
                     Bf.uncollected.fetch_sub(1, std::memory_order_acq_rel);
-                    qstate[q].store(QS_RUNNABLE, std::memory_order_relaxed);
+                    qstate(q).store(QS_RUNNABLE, std::memory_order_relaxed);
                     if (dbg) { t_ingest += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count(); ++n_ingest; }
                 }
                 ++n_resume;
@@ -2573,11 +2579,13 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                             size_t r = 0;
                             for (int32_t id : sq->inflight) { std::memcpy(&sq->inflight_q[r * N], &sq->qs[(size_t)id * N], sizeof(double) * N); ++r; }
                         }
-                        qstate[q].store(QS_REQUESTED, std::memory_order_release);
+                        qstate(q).store(QS_REQUESTED, std::memory_order_release);
+                        pend_cnt[(q / nworkers) % groups].v.fetch_add(1, std::memory_order_release);
                     }
                 } else {
                     done[q] = 1;
                     t_done[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    live_cnt[(q / nworkers) % groups].v.fetch_sub(1, std::memory_order_acq_rel);
                     remaining.fetch_sub(1, std::memory_order_acq_rel);
                 }
                 t_work += std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
@@ -2605,6 +2613,13 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         long depth_sum = 0;
         auto idle_since = std::chrono::steady_clock::now();
         std::chrono::steady_clock::time_point issued_at[kSets];
+        // SMPLX_DEBUG_TIMELINE: issue / landing times of batches 2000 .. 2059 (us since the first of them)
+        const bool timeline = getenv("SMPLX_DEBUG_TIMELINE") != nullptr;
+        struct Tl { double issue0, issue1, land, prelaunch, postlaunch; int n, depth; };
+        double tl_pre = 0, tl_post = 0;
+        std::vector<Tl> tl;
+        std::vector<int> tl_of_set(kSets, -1);
+        std::chrono::steady_clock::time_point tl0;
         while (remaining.load(std::memory_order_acquire) > 0 && error.load(std::memory_order_relaxed) == 0) {
             bool did = false;
             // retire landed batches in issue order
@@ -2614,12 +2629,13 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                 if (st == hipErrorNotReady) break;
                 if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
                 Bf.uncollected.store((int)Bf.queries.size(), std::memory_order_relaxed);
-                for (int q : Bf.queries) qstate[q].store(QS_LANDED, std::memory_order_release);
+                for (int q : Bf.queries) qstate(q).store(QS_LANDED, std::memory_order_release);
                 Bf.in_flight = false;
                 if (dbg) {
                     const auto nowt = std::chrono::steady_clock::now();
                     lat_sum += std::chrono::duration<double>(nowt - issued_at[oldest]).count();
                     if (in_flight == 1) idle_since = nowt;
+                    if (timeline && tl_of_set[oldest] >= 0) { tl[tl_of_set[oldest]].land = 1e6 * std::chrono::duration<double>(nowt - tl0).count(); tl_of_set[oldest] = -1; }
                 }
                 oldest = (oldest + 1) % kSets;
                 --in_flight;
@@ -2634,12 +2650,10 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                 // moment it appears gives many small batches (27 queries each with 128 live) and a query then waits for
                 // ~5 batch times per miss.  So a batch is issued when about half of the live queries are waiting:
                 // one half of them is on the GPU while the workers run the other half.
-                int live_g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pend_g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int q = 0; q < nq; ++q) {
-                    if (done[q]) continue;
-                    const int g = (q / nworkers) % groups;
-                    ++live_g[g];
-                    pend_g[g] += qstate[q].load(std::memory_order_acquire) == QS_REQUESTED ? 1 : 0;
+                int live_g[8], pend_g[8];
+                for (int g = 0; g < groups; ++g) {
+                    live_g[g] = live_cnt[g].v.load(std::memory_order_acquire);
+                    pend_g[g] = pend_cnt[g].v.load(std::memory_order_acquire);
                 }
                 // the group closest to its threshold (one group: every live query)
                 int pick = -1;
@@ -2653,12 +2667,13 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                 if (pick >= 0) {
                     for (int q = 0; q < nq; ++q) {
                         if ((q / nworkers) % groups != pick) continue;
-                        if (qstate[q].load(std::memory_order_acquire) != QS_REQUESTED) continue;
+                        if (qstate(q).load(std::memory_order_acquire) != QS_REQUESTED) continue;
                         row_of[q] = (long)total;
                         set_of[q] = next_set;
                         total += spaces[q]->inflight.size();
                         Nf.queries.push_back(q);
                     }
+                    pend_cnt[pick].v.fetch_sub((int)Nf.queries.size(), std::memory_order_acq_rel);
                 }
                 if (total > 0) {
                     const int B = (int)total;
@@ -2690,7 +2705,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         // a requesting query is not being touched by its worker: its committed states join the device table
                         if ((e = table_grow_if_needed(sq))) return e;
                         table_take_pending(sq, q, Nf.ins_items);
-                        qstate[q].store(QS_IN_FLIGHT, std::memory_order_relaxed);
+                        qstate(q).store(QS_IN_FLIGHT, std::memory_order_relaxed);
                     }
                     K5Out k5;
                     k5.d_id = Nf.dv.id;
@@ -2719,6 +2734,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     if (B <= small_zero_copy_max && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
                         // one launch, no copies: parents, query indices and results live in pinned host memory
                         if (dbg) t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
+                        if (timeline) tl_pre = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
                         ZeroCopy zc;
                         zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h; zc.id = Nf.pv.id;
                         k5.items = (const int32_t*)(Nf.p_q.p + total * N);
@@ -2732,7 +2748,17 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                                                Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, !small_device, &k5))) return e;
                         HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));
                     }
+                    if (timeline) tl_post = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
                     HIP_TRY(hipEventRecord(Nf.done, Nf.stream));
+                    if (dbg && timeline && sweeps >= 2000 && sweeps < 2060) {
+                        if (tl.empty()) tl0 = i0;
+                        Tl x;
+                        x.issue0 = 1e6 * std::chrono::duration<double>(i0 - tl0).count();
+                        x.issue1 = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
+                        x.land = -1; x.n = (int)total; x.depth = in_flight; x.prelaunch = tl_pre; x.postlaunch = tl_post;
+                        tl_of_set[next_set] = (int)tl.size();
+                        tl.push_back(x);
+                    }
                     if (dbg) {
                         issued_at[next_set] = i0;
                         depth_sum += in_flight;
@@ -2756,6 +2782,8 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                                  "issue-to-landing %.1f us on average; %.2f batches already in flight at issue; of the issuing, %.3fs before the launch call\n",
                          sweeps, sweeps ? (double)states / sweeps : 0.0, t_issue, t_gpu_idle, sweeps ? 1e6 * lat_sum / sweeps : 0.0,
                          sweeps ? (double)depth_sum / sweeps : 0.0, t_pack);
+        for (const Tl& x : tl) fprintf(stderr, "[smplx timeline] issue %.0f..%.0f us, landed %.0f us, %d states, %d in flight before; pack %.0f us, launch call %.0f us, record %.0f us\n", x.issue0, x.issue1, x.land, x.n, x.depth,
+                                           x.prelaunch, x.postlaunch - x.prelaunch, (x.issue1 - x.issue0) - x.postlaunch);
         return SMPLX_OK;
     };
 
