@@ -364,6 +364,52 @@ def main():
         out["k2"] = k2
         del dq, dv, dl
 
+        # ---- the reference's own collision benchmark shape ("collision checks / s, PR2 right arm, uniformly
+        # random joint states", benchmark_cc.cpp:234-301): the PR2 right arm built from data files (the reference's
+        # collision_model_pr2.yaml + a URDF subset, tests/golden/) in an EMPTY world ----
+        gold = os.path.join(ROOT, "tests", "golden")
+        try:
+            pr2 = scenes.pr2_right_arm_text(open(os.path.join(gold, "collision_model_pr2.yaml")).read(),
+                                            open(os.path.join(gold, "pr2_right_arm.urdf")).read(),
+                                            json.load(open(os.path.join(gold, "pr2_right_arm_acm.json")))["allowed_pairs"])
+        except OSError:
+            pr2 = None
+        if pr2 is not None:
+            import dataclasses
+            lim = [(-2.1353981634, 0.564601836603), (-0.3536, 1.2963), (-3.75, 0.65), (-2.1213, -0.15), (-np.pi, np.pi), (-2.0, -0.1),
+                   (-np.pi, np.pi)]
+            g_empty = scenes.build_grid((-0.75, -1.5, 0.0), (150, 150, 150), 0.02, 0.4, [])
+            cfg_p = dataclasses.replace(cfg, name="pr2_empty_world", robot_text=pr2, grid=g_empty)
+            sp = capi.Space.from_config(cfg_p, batch_states=256)
+            Qp = scenes.benchmark_states(lim, n2, 12345)
+            dq = torch.from_numpy(Qp).to(dev)
+            dv = torch.zeros(n2, dtype=torch.uint8, device=dev)
+            dl = torch.zeros(n2, dtype=torch.int32, device=dev)
+            for _ in range(2):
+                sp.state_valid_batch_device(dq.data_ptr(), n2, dv.data_ptr(), dl.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(reps):
+                sp.state_valid_batch_device(dq.data_ptr(), n2, dv.data_ptr(), dl.data_ptr(), stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            msp = e0.elapsed_time(e1) / reps
+            kp = {"robot": "PR2 right arm from tests/golden (collision_model_pr2.yaml of the reference, URDF subset, right-arm rows of "
+                           "the demo's allowed-collision matrix): 23 leaf spheres on 8 links, 5 checked link pairs",
+                  "world": "empty 150^3 grid @ 0.02 m", "configs": n2, "kernel_ms": round(msp, 4),
+                  "collision_checks_per_s": round(n2 / (msp * 1e-3), 1), "valid_fraction": round(int(dv.sum(dtype=torch.int64).item()) / n2, 4)}
+            if Oracle is not None:
+                o = Oracle(cfg_p)
+                o.set_order(chain=True)
+                ns = min(n2, 200000)
+                ok_c, lk_c, sec = o.state_valid_batch_timed(Qp[:ns])
+                kp["cpu_checks_per_s_one_core"] = round(ns / sec, 1)
+                kp["parity"] = {"valid_bits_equal": bool(np.array_equal(ok_c, dv[:ns].cpu().numpy())),
+                                "lookups_equal_on_valid": bool(np.array_equal(lk_c[ok_c == 1], dl[:ns].cpu().numpy()[ok_c == 1]))}
+                del o
+            out["k2_pr2"] = kp
+            del dq, dv, dl, sp
+
     if single and Oracle is not None:
         o = Oracle(cfg)
         o.set_goal_joint(q_goal, cfg.goal_tol)
