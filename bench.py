@@ -398,6 +398,11 @@ def main():
                            "the demo's allowed-collision matrix): 23 leaf spheres on 8 links, 5 checked link pairs",
                   "world": "empty 150^3 grid @ 0.02 m", "configs": n2, "kernel_ms": round(msp, 4),
                   "collision_checks_per_s": round(n2 / (msp * 1e-3), 1), "valid_fraction": round(int(dv.sum(dtype=torch.int64).item()) / n2, 4)}
+            lkp = int(dl.sum(dtype=torch.int64).item())
+            kp_bytes = 4.0 * lkp + 8.0 * N * n2
+            kp["lookups"] = lkp
+            kp["roofline"] = {"bound": "hbm", "achieved": round(kp_bytes / (msp * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(kp_bytes / (msp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "traffic": None}
             if Oracle is not None:
                 o = Oracle(cfg_p)
                 o.set_order(chain=True)
