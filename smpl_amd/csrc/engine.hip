@@ -1069,24 +1069,34 @@ int issue_batch(smplx_space* s, int id)
 int ingest_row(smplx_space* s, const OutView& pv, size_t row, int* evals_out)
 {
     const int N = s->N, M = s->M;
+    // the flags first (25 bytes): how many records, then ONE growth of each array and plain copies into it
     int cnt = 0, evals = 0;
+    const unsigned char* fl = &pv.flags[row * M];
     for (int p = 0; p < M; ++p) {
-        const size_t k = row * M + p;
-        const unsigned char f = pv.flags[k];
-        if (!(f & SMPLX_F_INACTIVE)) ++evals;
-        if (!(f & SMPLX_F_VALID)) continue;
-        smplx_space::Rec r;
-        r.cost = s->actions.dev.cost[p];
-        r.h = pv.h[k];
-        r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
-        r.known = s->d_table ? pv.id[k] : -1;
-        r.prim = p;
-        s->recs.push_back(r);
-        s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
-        s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
-        ++cnt;
+        evals += (fl[p] & SMPLX_F_INACTIVE) ? 0 : 1;
+        cnt += (fl[p] & SMPLX_F_VALID) ? 1 : 0;
     }
     *evals_out = evals;
+    if (cnt == 0) return 0;
+    const size_t r0 = s->recs.size();
+    s->recs.resize(r0 + cnt);
+    s->rec_coord.resize((r0 + cnt) * (size_t)N);
+    s->rec_q.resize((r0 + cnt) * (size_t)N);
+    size_t r = r0;
+    for (int p = 0; p < M; ++p) {
+        const unsigned char f = fl[p];
+        if (!(f & SMPLX_F_VALID)) continue;
+        const size_t k = row * M + p;
+        smplx_space::Rec& rec = s->recs[r];
+        rec.cost = s->actions.dev.cost[p];
+        rec.h = pv.h[k];
+        rec.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
+        rec.known = s->d_table ? pv.id[k] : -1;
+        rec.prim = p;
+        std::memcpy(&s->rec_coord[r * N], &pv.coord[k * N], sizeof(int32_t) * N);
+        std::memcpy(&s->rec_q[r * N], &pv.sq[k * N], sizeof(double) * N);
+        ++r;
+    }
     return cnt;
 }
 
