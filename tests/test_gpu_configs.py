@@ -411,3 +411,35 @@ def test_config3_pr2_right_arm_as_data(cfg3_pr2):
     assert o.set_start(cfg.start) == s.set_start(cfg.start) == 1
     eo, go = _same_search(o, s, 100.0, 2500, 2500)
     assert go["solved"] == 1 and go["cost"] > 0
+
+
+@pytest.mark.parametrize("env", [{"SMPLX_ISSUE_GROUPS": "2", "SMPLX_ISSUE_PERCENT": "70"}, {"SMPLX_MULTI_SMALL_MAX": "0"},
+                                 {"SMPLX_ISSUE_PERCENT": "1", "SMPLX_SMALL_MAX": "8"}])
+def test_multi_query_driver_switches_do_not_change_results(small_cfg, monkeypatch, env):
+    """The asynchronous driver's scheduling switches (issue groups and threshold, which batches take the single-launch
+    zero-copy kernel) decide WHEN and HOW batches are evaluated, never what a query computes: eight queries through
+    smplx_plan_multi under each setting equal their solo runs."""
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    DEG = np.pi / 180.0
+    cells = [[-49, 7, 21, -14, -8, -12, 16], [-21, 7, 14, -7, 8, -4, 12], [-35, 14, 7, -14, 4, -8, 8], [-42, 10, 14, -10, 0, -8, 12],
+             [-28, 7, 7, -7, 4, -4, 4], [-14, 14, 21, -21, -8, 0, 8], [-56, 0, 14, -7, 0, -12, 16], [-7, 7, 28, -14, 8, -8, 0]]
+    goals = [[cfg.start[i] + c * DEG for i, c in enumerate(cs)] for cs in cells]
+    grid = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
+    model = capi.Model(cfg.robot_text)
+
+    def make():
+        out = []
+        for g in goals:
+            sp = capi.Space(model, grid, cfg.mprim, cfg.params, 512)
+            sp.set_goal_joint(g, cfg.goal_tol); sp.set_start(cfg.start)
+            out.append(sp)
+        return out
+    solo = [sp.plan(5.0, 1.0, 1.0, True, True, 3000, 2000) for sp in make()]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    multi, _ = capi.Space.plan_multi(make(), 5.0, 1.0, 1.0, True, True, 3000, 2000, host_threads=3)
+    for a, b in zip(solo, multi):
+        assert a["solved"] == b["solved"] and a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"])
+        assert np.array_equal(a["path"], b["path"]) and a["committed_succ_evals"] == b["committed_succ_evals"]
