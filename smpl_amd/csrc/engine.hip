@@ -723,7 +723,9 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
                            k.work, k.work_count, k.capacity, stab, state_q);
         if (ev) (void)hipEventRecord(ev[0], stream);
-        const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK);
+        // (SMPLX_CONFIGS_GRID_X2=1: room for two threads per configuration, kernels.hip const_chain ROLE 1 / 2 -- an experiment)
+        const int grid_x = getenv("SMPLX_CONFIGS_GRID_X2") ? 2 : 1;
+        const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK) * grid_x;
         KLAUNCH(s, K_PIPE_CONFIGS, k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, k.work, k.work_count,
                            k.capacity);

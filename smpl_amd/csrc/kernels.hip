@@ -543,11 +543,56 @@ __device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, con
 }
 
 // PT = the tree whose root lookup was issued at an earlier joint and has not been looked at yet (-1: none)
-template <int J, int PT, bool Known = false>
+// Split of one configuration over two threads of DIFFERENT waves (k_pipe_configs, ROLE 1 and 2; 0 = the whole check):
+// the trees in chain order are cut in two halves.  ROLE 1 walks the chain up to the last tree of the first half and
+// checks those trees against the grid; ROLE 2 walks the whole chain, computes every root position (the checked link
+// pairs need them) but looks up only the trees of the second half, and does the pairs.  Each half is shorter than the
+// whole, and a B = 4096 launch has SIMDs to spare for twice the waves.  A valid configuration's lookup tally is the sum
+// of the two (both add into the same counter); either half can flag the collision.
+// MEASURED (B = 4096, identical results, all parity tests green): 27.3 us against 22.2 us unsplit -- twice the blocks to
+// dispatch and stage, the FK of the first half done twice, and the halves are not the critical path the single-wave
+// picture suggested.  Kept behind -DSMPLX_SPLIT_CONFIGS (SMPLX_RTC_DEFINES) + SMPLX_CONFIGS_GRID_X2=1; off by default.
+constexpr int CM_SPLIT = (CM_NT + 1) / 2;          // trees in the first half
+template <int J>
+constexpr int cm_trees_before()
+{
+    int n = 0;
+    for (int j = 0; j < J && j < CM_NJ; ++j) n += CM_TREE[j] >= 0 ? 1 : 0;
+    return n;
+}
+constexpr int cm_last_joint_of_first_half()
+{
+    int n = 0;
+    for (int j = 0; j < CM_NJ; ++j)
+        if (CM_TREE[j] >= 0 && ++n == CM_SPLIT) return j;
+    return CM_NJ - 1;
+}
+
+// the root position of tree T_ for the link transform in C.T (the expression of issue_root, without the lookup)
+template <int T_>
+__device__ __forceinline__ void root_position(const ChainState& C, double root_p[3])
+{
+    constexpr double cx = CM_ROOT_CX[T_], cy = CM_ROOT_CY[T_], cz = CM_ROOT_CZ[T_];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double acc = 0.0;
+        bool have = false;
+        if constexpr (cx != 0.0) { acc = C.T[4 * i + 0] * cx; have = true; }
+        if constexpr (cy != 0.0) { acc = have ? acc + C.T[4 * i + 1] * cy : C.T[4 * i + 1] * cy; have = true; }
+        if constexpr (cz != 0.0) { acc = have ? acc + C.T[4 * i + 2] * cz : C.T[4 * i + 2] * cz; have = true; }
+        root_p[i] = have ? acc + C.T[4 * i + 3] : C.T[4 * i + 3];
+    }
+}
+
+template <int J, int PT, bool Known = false, int ROLE = 0>
 __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                             ChainState& C, int& lookups)
 {
-    if constexpr (J < CM_NJ) {
+    if constexpr (ROLE == 1 && J > cm_last_joint_of_first_half()) {
+        // first half: nothing beyond its last tree concerns it
+        if constexpr (PT >= 0) return resolve_root<PT>(M, L, g, C, lookups);
+        else return true;
+    } else if constexpr (J < CM_NJ) {
         constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J], tree = CM_TREE[J];
         if constexpr (src >= 0) {
 #pragma unroll
@@ -569,19 +614,24 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         }
         if constexpr (tree >= 0) {
             double rp[3];
+            constexpr bool first_half = cm_trees_before<J>() < CM_SPLIT;
+            constexpr bool look = ROLE == 0 || (ROLE == 1 && first_half) || (ROLE == 2 && !first_half);
 #ifdef ABL_NO_TREES
             rp[0] = C.T[3]; rp[1] = C.T[7]; rp[2] = C.T[11];
 #else
-            issue_root<tree, Known>(g, C, lookups, rp);
+            if constexpr (look) issue_root<tree, Known>(g, C, lookups, rp);
+            else root_position<tree>(C, rp);
 #endif
-            constexpr int slot = CM_ROOT_SLOT[tree];
-            if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
+            if constexpr (ROLE != 1) {
+                constexpr int slot = CM_ROOT_SLOT[tree];
+                if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
 #ifndef ABL_NO_PAIRS
-            const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
+                const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
 #endif
-            return const_chain<J + 1, tree, Known>(M, L, g, C, lookups);
+            }
+            return const_chain<J + 1, look ? tree : -1, Known, ROLE>(M, L, g, C, lookups);
         } else {
-            return const_chain<J + 1, -1, Known>(M, L, g, C, lookups);
+            return const_chain<J + 1, -1, Known, ROLE>(M, L, g, C, lookups);
         }
     } else {
         if constexpr (PT >= 0) {
@@ -790,6 +840,7 @@ __device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, 
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
 // the configuration's joint values are already staged in the thread's LDS slots (stage_config or the caller itself)
+template <int ROLE = 0>
 __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                                     const EdgeRef& e, int& lookups)
 {
@@ -812,7 +863,8 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
         C.pair_hit = false; C.recheck_all = false; C.P = P;
         C.pd2 = 0;
 #if !defined(SMPLX_CHAIN_SWEEP) || defined(ABL_NO_TREES) || defined(ABL_NO_LOOKUP)   // measured: the sweep is SLOWER (27.2 vs 23.7 us), see its comment
-        if (!const_chain<0, -1>(M, L, g, C, lookups)) return false;
+        if (!const_chain<0, -1, false, ROLE>(M, L, g, C, lookups)) return false;
+        if constexpr (ROLE == 1) return true;   // the pairs belong to the other half
 #else
         const_chain_issue<0>(M, L, g, C);
         int tally = 0;
@@ -1616,7 +1668,18 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
         pre[k + 1] = pre[k] + c;
     }
     const long long total = (long long)B + pre[SMPLX_WORK_SHARDS];
+#if defined(SMPLX_CONST_MODEL) && !defined(SMPLX_CHAIN_SWEEP) && defined(SMPLX_SPLIT_CONFIGS)
+    // two threads per configuration (const_chain ROLE 1 / 2) when the launch has room for them: the second-half roles take
+    // the first tpad threads, the first-half roles the next tpad, so that every block (and wave) has one role
+    const long long tpad = (total + BLOCK - 1) / BLOCK * BLOCK;
+    const bool split = CM_NT >= 2 && 2 * tpad <= (long long)gridDim.x * BLOCK;
+    if ((long long)blockIdx.x * BLOCK >= (split ? 2 * tpad : total)) return;
+#else
+    const bool split = false;
+    const long long tpad = 0;
+    (void)split; (void)tpad;
     if ((long long)blockIdx.x * BLOCK >= total) return;   // whole block idle: skip staging the model
+#endif
 #ifdef SMPLX_CONST_MODEL
     // Per-robot build: the launch covers every item (engine.hip sizes the grid for B + 3 B M items and k_pipe_setup never
     // lists more), one item per thread.  A block's life is a chain of dependent memory round trips of ~1 us each --
@@ -1626,7 +1689,9 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     if (total <= (long long)gridDim.x * BLOCK) {
         const int nprims = S->actions.nprims;
         constexpr int nv = CM_NV;
-        const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        const long long i_raw = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        const int role = split ? (i_raw < tpad ? 2 : 1) : 0;      // uniform per block
+        const long long i = role == 1 ? i_raw - tpad : i_raw;
         unsigned long long it = SMPLX_WORK_BLANK;
         if (i >= B && i < total) {
             const int li = (int)(i - B);
@@ -1665,9 +1730,16 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             lds_d(L, L.q_base + v) = q;
         }
 #endif
-        const bool ok = config_valid_staged(M, L, grid, e, lk);
+        bool ok;
+#if !defined(SMPLX_CHAIN_SWEEP) && defined(SMPLX_SPLIT_CONFIGS)
+        if (role == 2) ok = config_valid_staged<2>(M, L, grid, e, lk);
+        else if (role == 1) ok = config_valid_staged<1>(M, L, grid, e, lk);
+        else
+#endif
+            ok = config_valid_staged<0>(M, L, grid, e, lk);
         if (is_state) {
-            state_lookups[i] = lk;
+            if (role == 0) state_lookups[i] = lk;
+            else atomicAdd(&state_lookups[i], lk);   // zeroed by k_pipe_setup; the two halves add up
             if (!ok) state_bad[i] = 1;
         } else {
             atomicAdd(&edge_lookups[edge], lk);

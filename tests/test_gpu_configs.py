@@ -443,3 +443,26 @@ def test_multi_query_driver_switches_do_not_change_results(small_cfg, monkeypatc
     for a, b in zip(solo, multi):
         assert a["solved"] == b["solved"] and a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"])
         assert np.array_equal(a["path"], b["path"]) and a["committed_succ_evals"] == b["committed_succ_evals"]
+
+
+def test_two_threads_per_configuration_build_gives_the_same_results(small_cfg, monkeypatch):
+    """-DSMPLX_SPLIT_CONFIGS + SMPLX_CONFIGS_GRID_X2=1 (an experiment kept as a switch: measured slower): every
+    configuration of the pipeline's collision kernel is checked by two threads of different waves, one per half of the
+    trees; verdicts and the lookup tallies of valid edges must be those of the whole check."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    monkeypatch.setenv("SMPLX_RTC_DEFINES", "-DSMPLX_SPLIT_CONFIGS")
+    monkeypatch.setenv("SMPLX_CONFIGS_GRID_X2", "1")
+    s = capi.Space.from_config(cfg, batch_states=256, no_small_kernel=True)
+    ok, note = s.specialized()
+    if not ok:
+        pytest.skip("generic kernels in use: the split only exists in the per-robot build (" + note + ")")
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    _same_search(o, s, 5.0, 3000, 3000)
+    Q = scenes.random_states(scenes.ARM7_LIMITS, 300, 6)
+    o.set_order(chain=True)
+    _compare_batch(o, s, Q)
