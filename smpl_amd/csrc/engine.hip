@@ -2658,11 +2658,9 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
             BatchBuffers& Nf = sets[next_set];
             if (in_flight < kInFlight && !Nf.in_flight && Nf.uncollected.load(std::memory_order_acquire) == 0) {
                 const auto i0 = std::chrono::steady_clock::now();
-                // A batch costs the GPU about 80 us whatever its size (rocprofv3: 36 us of kernels, the rest copies and
-                // dependencies), and batches of different streams were not seen to overlap.  Taking every request the
-                // moment it appears gives many small batches (27 queries each with 128 live) and a query then waits for
-                // ~5 batch times per miss.  So a batch is issued when about half of the live queries are waiting:
-                // one half of them is on the GPU while the workers run the other half.
+                // A batch has a fixed cost (issuing ~15 us, ~40 us on the GPU whatever its size).  Taking every request the
+                // moment it appears gives many small batches and a query then waits for several batch times per miss, so a batch
+                // is issued when issue_percent (45 %) of the live queries are waiting; the two counters are kept by the workers.
                 int live_g[8], pend_g[8];
                 for (int g = 0; g < groups; ++g) {
                     live_g[g] = live_cnt[g].v.load(std::memory_order_acquire);
