@@ -228,7 +228,9 @@ struct smplx_space {
     bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
     int small_batch_max = 512;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
     double small_latency_limit = 70e-6;   // SMPLX_SMALL_KERNEL=always lifts it, =never disables the single-launch kernel
-    bool small_zero_copy = true;          // SMPLX_SMALL_ZERO_COPY=0: the single-launch kernel with DMA copies instead of host-memory I/O
+    bool small_zero_copy = true;
+    bool small_split = false;       // SMPLX_SMALL_SPLIT=1: two waypoint-lane sets per state in the single-launch kernel (measured: waypoint
+                                    // phase 13.4 -> 11.5 us, nothing end to end: the second-half role still does 3/4 of the work)          // SMPLX_SMALL_ZERO_COPY=0: the single-launch kernel with DMA copies instead of host-memory I/O
     DevBuf<unsigned long long> b_counters;
     PinBuf<double> p_q;
     DevBuf<unsigned char> b_out;   // packed outputs of a planner batch (OutView)
@@ -684,8 +686,17 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int bs = blocks_for(B, SMPLX_BLOCK);
     const int be = blocks_for((long long)B * s->M, SMPLX_BLOCK);
     const int64_t* norefs = nullptr;
-    const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    int small_block = smplx_small_block(s->M);
+    size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const int roll_block = small_block;
+    const size_t roll_lds = small_lds;
+    {
+        // a handful of states on per-robot kernels: two waypoint-lane sets per state (kernels.hip k_small_batch); the larger
+        // block holds a CU's LDS almost alone, so not for the batches of hundreds of states of the multi-query driver
+        const int sb = smplx_small_block_split(s->M);
+        const size_t sl = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, sb);
+        if (s->ks.specialized && s->small_split && B <= 64 && sb <= 512 && sl <= 150 * 1024 && small_block <= 512) { small_block = sb; small_lds = sl; }
+    }
     SmplxRollDev noroll;
     std::memset(&noroll, 0, sizeof(noroll));
     noroll.host_sel = s->small_trace;   // -DSMPLX_SMALL_TRACE builds only: phase clock of block 0
@@ -750,7 +761,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
             rd.w = s->roll_w;
             rd.out_sel = d_sel;
             rd.host_sel = zero_copy ? zero_copy->sel : (int32_t*)nullptr;
-            KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(RK), dim3(small_block), small_lds, stream, s->d_space, (const double*)d_sq, norefs, Btot,
+            KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(RK), dim3(roll_block), roll_lds, stream, s->d_space, (const double*)d_sq, norefs, Btot,
                     k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
                     zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
                     zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
@@ -1453,6 +1464,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if (params->reserved & 4) s->small_batch_max = 0;
     if (const char* e = getenv("SMPLX_SPEC_CHILDREN")) s->spec_children = e[0] != '0';
     if (const char* e = getenv("SMPLX_SMALL_ZERO_COPY")) s->small_zero_copy = e[0] != '0';
+    if (const char* e = getenv("SMPLX_SMALL_SPLIT")) s->small_split = e[0] != '0';
     if (const char* e = getenv("SMPLX_SMALL_MAX")) s->small_batch_max = std::max(0, atoi(e));
     s->dbg_birth_on = getenv("SMPLX_DEBUG_TIMING") != nullptr;
     if (s->dbg_birth_on && hipHostMalloc((void**)&s->small_trace, 8 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess)

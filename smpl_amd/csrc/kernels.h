@@ -16,6 +16,8 @@
 // small-batch kernel: 7 waypoint lanes per primitive + the state's own lane in whole "config" waves, then one more wave
 // whose lanes are the primitives' bookkeeping lanes + the goal-distance lane (nprims + 1 <= 64)
 static inline int smplx_small_block(int nprims) { return ((nprims * 7 + 1) + 63) / 64 * 64 + 64; }
+// with two waypoint-lane sets per state (k_small_batch: one per half of the trees)
+static inline int smplx_small_block_split(int nprims) { return 2 * (((nprims * 7 + 1) + 63) / 64 * 64) + 64; }
 static inline size_t smplx_lds_bytes_n(size_t blob_bytes, int nroot, int nslots, int nvars, int nthreads)
 {
     return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * nthreads + (size_t)SMPLX_STACK_BYTES * nthreads;

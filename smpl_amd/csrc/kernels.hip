@@ -970,13 +970,26 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
     return !pair_hit;
 }
 
+template <int ROLE = 0>
 __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                              const EdgeRef& e, int& lookups)
 {
 #ifndef ABL_NO_FK
     stage_config(M, L, e);
 #endif
-    return config_valid_staged(M, L, g, e, lookups);
+    return config_valid_staged<ROLE>(M, L, g, e, lookups);
+}
+
+// role of a waypoint lane (k_small_batch with two lane sets per state): wave-uniform dispatch
+__device__ __forceinline__ bool config_valid_role(int role, const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
+                                                  const EdgeRef& e, int& lookups)
+{
+#if defined(SMPLX_CONST_MODEL) && !defined(SMPLX_CHAIN_SWEEP)
+    if (role == 2) return config_valid<2>(M, L, g, e, lookups);
+    if (role == 1) return config_valid<1>(M, L, g, e, lookups);
+#endif
+    (void)role;
+    return config_valid<0>(M, L, g, e, lookups);
 }
 
 // CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
@@ -2002,7 +2015,20 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const int nprims = A.nprims, nv = MV_NVARS(M);
     const int t = threadIdx.x;
     const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
-    const int book0 = (ncfg + 63) / 64 * 64;                  // first lane of the bookkeeping wave
+    const int cfgw = (ncfg + 63) / 64 * 64;
+    // Two lane sets per state when the block was launched with room for them (engine.hip: per-robot build, a handful of
+    // states): every waypoint is checked by two lanes of different waves, one per half of the trees (const_chain ROLE 2
+    // in lanes [0, cfgw), ROLE 1 in [cfgw, 2 cfgw)).  Measured (SMPLX_SMALL_SPLIT=1): the waypoint phase goes from 13.4 to
+    // 11.5 us and the search gains nothing -- the second-half role still walks the whole chain, computes every root
+    // position and does the pairs, three quarters of the work.  Off by default.
+#if defined(SMPLX_CONST_MODEL) && !defined(SMPLX_CHAIN_SWEEP)
+    const bool split = CM_NT >= 2 && (int)blockDim.x >= 2 * cfgw + 64;
+#else
+    const bool split = false;
+#endif
+    const int book0 = split ? 2 * cfgw : cfgw;                // first lane of the bookkeeping wave
+    const int role = split ? (threadIdx.x < cfgw ? 2 : 1) : 0;
+    const int tc = (split && (int)threadIdx.x >= cfgw) ? (int)threadIdx.x - cfgw : (int)threadIdx.x;   // lane within its set
     long long parent_at = refs ? refs[si] : (int64_t)si;      // where the parent's joint values sit in Q (units of nv)
     if (roll.on) {
         // Rollout row (N2: expansion continued on the device): the parent is a SUCCESSOR evaluated by an earlier launch
@@ -2051,6 +2077,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     }
     if (t < nv) s_parent[t] = Q[parent_at * nv + t];
     if (t < nprims) { s_edge_bad[t] = 0; s_edge_lk[t] = 0; }
+    if (t == 0) { s_state_bad = 0; s_state_lookups = 0; }
     __syncthreads();
     SMALL_MARK(2);
     const double* parent = s_parent;
@@ -2106,9 +2133,9 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 
     int h = 0, is_goal = 0, early_id = -1, W = 0;
     bool limits_ok = false;
-    if (t < ncfg - 1) {
+    if (t < book0 && tc < ncfg - 1) {
         // ---- config lanes: one waypoint each ----
-        const int p = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
+        const int p = tc / SMPLX_SMALL_LANES, slot = tc % SMPLX_SMALL_LANES;
         const int ty = A.type[p];
         const bool act = ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
         if (act && mprim_active(A, s_goal_dist, ty)) {
@@ -2134,23 +2161,21 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                     EdgeRef e;
                     e.start = parent; e.finish = sq;
                     e.alpha = (double)wp * (1.0 / (double)(Wc - 1));
-                    const bool ok = config_valid(M, L, grid, e, my_lk);
+                    const bool ok = config_valid_role(role, M, L, grid, e, my_lk);
                     my_bad = ok ? 0 : 1;
                 }
                 if (my_bad) atomicOr(&s_edge_bad[p], 1);
                 if (my_lk) atomicAdd(&s_edge_lk[p], my_lk);
             }
         }
-    } else if (t == ncfg - 1) {
+    } else if (t < book0 && tc == ncfg - 1) {
         // ---- the state itself: waypoint 0 of each edge (same code path as the other lanes of its wave) ----
         EdgeRef e;
         e.start = parent; e.finish = parent; e.alpha = 0.0;
         int lk = 0;
-        const bool ok = config_valid(M, L, grid, e, lk);
-        s_state_bad = ok ? 0 : 1;
-        s_state_lookups = lk;
-        state_bad_out[si] = ok ? 0 : 1;
-        state_lookups_out[si] = lk;
+        const bool ok = config_valid_role(role, M, L, grid, e, lk);
+        if (!ok) atomicOr(&s_state_bad, 1);
+        if (lk) atomicAdd(&s_state_lookups, lk);
     } else if (book && have_action) {
         // ---- bookkeeping lane of primitive bp: limits, waypoint count, coordinates, planning-link FK, goal test, heuristic ----
         const double* sq = s_sq[bp];
@@ -2194,6 +2219,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     SMALL_MARK(4);
 
     // ---- bookkeeping lanes: the verdict of their edge ----
+    if (bp == 0) { state_bad_out[si] = (unsigned char)s_state_bad; state_lookups_out[si] = s_state_lookups; }
     if (book) {
         const long long eid = (long long)si * nprims + bp;
         const int* sc = out_coord + eid * nv;

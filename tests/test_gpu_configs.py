@@ -466,3 +466,22 @@ def test_two_threads_per_configuration_build_gives_the_same_results(small_cfg, m
     Q = scenes.random_states(scenes.ARM7_LIMITS, 300, 6)
     o.set_order(chain=True)
     _compare_batch(o, s, Q)
+
+
+def test_single_launch_kernel_with_two_lane_sets_gives_the_same_search(small_cfg, monkeypatch):
+    """SMPLX_SMALL_SPLIT=1 (an experiment kept as a switch): in the single-launch kernel every waypoint is checked by two
+    lanes of different waves, one per half of the trees.  Same search as the oracle's."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = small_cfg
+    monkeypatch.setenv("SMPLX_SMALL_SPLIT", "1")
+    monkeypatch.setenv("SMPLX_SMALL_KERNEL", "always")
+    s = capi.Space.from_config(cfg, batch_states=64)
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert o.set_start(cfg.start) == s.set_start(cfg.start)
+    _same_search(o, s, 5.0, 3000, 3000)
+    Q = scenes.random_states(scenes.ARM7_LIMITS, 48, 8)
+    o.set_order(chain=True)
+    _compare_batch(o, s, Q)
