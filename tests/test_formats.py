@@ -128,3 +128,18 @@ def test_pr2_right_arm_as_data_compiles_to_the_surveyed_model(cfg3_pr2):
     m = capi.Model(text)
     assert (m.nvars, m.ntrees) == (7, 8)
     assert m.npairs == 5
+
+
+def test_pr2_right_arm_kinematics_known_answers(cfg3_pr2):
+    """Known answers for the URDF subset (hand arithmetic on the joint origins): with every joint at zero the arm points
+    along +x from the shoulder, so r_gripper_palm_link sits at torso + (0, -0.188, 0) + (0.1 + 0.4 + 0.321, 0, 0); with the
+    shoulder pan at +90 degrees the same chain points along +y."""
+    from oracle_binding import Oracle
+    o = Oracle(cfg3_pr2)
+    p0 = np.array(o.planning_fk([0.0] * 7))
+    assert np.allclose(p0, [0.821, -0.188, 0.8], atol=1e-12)
+    p1 = np.array(o.planning_fk([np.pi / 2, 0, 0, 0, 0, 0, 0]))
+    assert np.allclose(p1, [0.0, -0.188 + 0.821, 0.8], atol=1e-12)
+    # elbow bent by -90 degrees about y: the forearm points along +z from the elbow at x = 0.5
+    p2 = np.array(o.planning_fk([0, 0, 0, -np.pi / 2, 0, 0, 0]))
+    assert np.allclose(p2, [0.5, -0.188, 0.8 + 0.321], atol=1e-12)
