@@ -2550,7 +2550,9 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
     std::vector<int> set_of(nq, -1);
     std::atomic<int> remaining{nq}, error{0};
     std::string error_msg;
-    for (int q = 0; q < nq; ++q) { qstate(q).store(QS_RUNNABLE); S[q].defer_issue = true; S[q].pause_after = 16; }
+    int pause_after = 16;   // expansions without a miss before a query hands its worker to the next one (SMPLX_PAUSE_AFTER)
+    if (const char* e = getenv("SMPLX_PAUSE_AFTER")) pause_after = std::max(1, atoi(e));
+    for (int q = 0; q < nq; ++q) { qstate(q).store(QS_RUNNABLE); S[q].defer_issue = true; S[q].pause_after = pause_after; }
     {
         std::vector<const SmplxSpaceDev*> tab(nq);
         for (int q = 0; q < nq; ++q) tab[q] = spaces[q]->d_space;
