@@ -102,14 +102,17 @@ typedef struct smplx_params {
     int32_t use_long_and_short;
     double padding;                   /* SelfCollisionModel m_padding, default 0 */
     int32_t batch_states;             /* frontier batch B (0 = default 4096) */
-    int32_t reserved;                 /* bit 0: fused mode -- one GPU thread walks a whole edge in the
-                                         reference's waypoint order (exact reference lookup tallies);
-                                         default 0: waypoint-parallel pipeline (same results, faster);
-                                         bit 1: test hook -- a tiny work list, so that most edges take the
-                                         deferred (fused) pass of the pipeline; bit 2: never use the single-launch
-                                         kernel for small batches (<= 256 states); bit 3: generic kernels only, no
-                                         per-robot build (see smplx_space_specialized) */
+    int32_t flags;                    /* SMPLX_SPACE_* bits below; 0 = defaults */
 } smplx_params;
+
+/* smplx_params.flags: which kernels serve the space.  Results are identical whatever the bits (the parity suite runs
+ * every combination); they exist for A/B measurements and for callers that want the reference's own lookup tallies. */
+enum {
+    SMPLX_SPACE_FUSED = 1,            /* one GPU thread walks a whole edge in the reference's waypoint order (exact
+                                         reference lookup tallies also on colliding edges); default: waypoint-parallel */
+    SMPLX_SPACE_NO_SMALL_KERNEL = 4,  /* small batches (<= 512 states) go through the four-kernel pipeline too */
+    SMPLX_SPACE_GENERIC_KERNELS = 8   /* no per-robot kernel build (see smplx_space_specialized) */
+};
 
 /* RobotPlanningSpace::init + insertHeuristic (smpl/include/smpl/graph/robot_planning_space.h:68,89;
  * smpl/src/graph/manip_lattice.cpp:72-149; smpl/src/heuristic/bfs_heuristic.cpp:52-71,331-353;

@@ -43,7 +43,7 @@ class Params(C.Structure):
                 ("use_short_dist_mprims", C.c_int32), ("short_dist_mprims_thresh", C.c_double),
                 ("use_xyzrpy_snap_mprim", C.c_int32), ("xyzrpy_snap_dist_thresh", C.c_double),
                 ("xy_rotate_by_var3", C.c_int32), ("use_long_and_short", C.c_int32), ("padding", C.c_double),
-                ("batch_states", C.c_int32), ("reserved", C.c_int32)]
+                ("batch_states", C.c_int32), ("flags", C.c_int32)]
 
 
 class SearchParams(C.Structure):
@@ -226,10 +226,12 @@ class Space:
         P.use_long_and_short = int(params.use_long_and_short)
         P.padding = padding
         P.batch_states = batch_states
-        P.reserved = ((1 if fused else 0) | (2 if tiny_work_list else 0) | (4 if no_small_kernel else 0) |
-                      (8 if generic_kernels else 0))
+        P.flags = (1 if fused else 0) | (4 if no_small_kernel else 0) | (8 if generic_kernels else 0)
         self.h = C.c_void_p()
         _chk(lib().smplx_space_create(model.h, grid.h, mprim_text.encode(), C.byref(P), C.byref(self.h)))
+        if tiny_work_list:   # test hook (smpl_amd/csrc/test_hooks.h; not part of include/smpl_amd.h)
+            lib().smplx_test_set_work_list_items.argtypes = [C.c_void_p, C.c_int]
+            _chk(lib().smplx_test_set_work_list_items(self.h, 8 * 16))
         self.N = lib().smplx_space_num_vars(self.h)
         self.M = lib().smplx_space_num_prims(self.h)
 

@@ -135,14 +135,6 @@ struct SmplxCompactDev {
     int32_t rec_b_bytes, pad;
 };
 
-// Rollout launch of k_small_batch (N2: expansion continued on the device; kernels.hip).  Block b of the launch produces
-// row row0 + b; its parent is the (b / rank_div + 1)-th best edge (rank_div 0: the best) of row base + (mod > 0 ? b % mod : b).
-struct SmplxRollDev {
-    int32_t on, row0, base, mod, rank_div, w;
-    int32_t* out_sel;            // per row: index (row * nprims + primitive) of the edge taken, -1 = nothing to continue from
-    int32_t* host_sel;           // optional pinned twin
-};
-
 struct SmplxGoalDev {
     int32_t type, pad;
     double angles[SMPLX_MAX_VARS];

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "model_compile.h"
 #include "specialize.h"
+#include "test_hooks.h"
 
 namespace {
 
@@ -163,11 +164,10 @@ struct OutView {
     int32_t* h = nullptr;
     int32_t* id = nullptr;      // K5: state id of the successor's coordinate in the device table, -1 = not there
     unsigned char* flags = nullptr;
-    int32_t* sel = nullptr;     // N2: per row, the edge a rollout row continued from (SmplxRollDev::out_sel)
     size_t bytes = 0;
 };
 
-inline OutView carve_out(unsigned char* base, size_t BM, int N, size_t rows = 0)
+inline OutView carve_out(unsigned char* base, size_t BM, int N)
 {
     OutView v;
     size_t o = 0;
@@ -175,7 +175,6 @@ inline OutView carve_out(unsigned char* base, size_t BM, int N, size_t rows = 0)
     v.coord = (int32_t*)(base + o); o += BM * N * sizeof(int32_t);
     v.h = (int32_t*)(base + o); o += BM * sizeof(int32_t);
     v.id = (int32_t*)(base + o); o += BM * sizeof(int32_t);
-    v.sel = (int32_t*)(base + o); o += (rows + 3) / 4 * 4 * sizeof(int32_t);
     v.flags = base + o; o += BM;
     v.bytes = (o + 15) / 16 * 16;
     return v;
@@ -222,15 +221,12 @@ struct smplx_space {
     DevBuf<double> b_q, b_q2, b_sq, b_xyz;
     DevBuf<unsigned char> b_flags, b_work;
     DevBuf<int32_t> b_coord, b_h, b_cost, b_lookups, b_way;
-    smplx::KernelSet ks;       // per-robot kernels (specialize.h), generic ones when params.reserved & 8 or SMPLX_SPECIALIZE=0
+    smplx::KernelSet ks;       // per-robot kernels (specialize.h), generic ones with SMPLX_SPACE_GENERIC_KERNELS or SMPLX_SPECIALIZE=0
     std::string specialize_note;   // why the per-robot build is absent, if it is
-    bool fused_mode = false;   // params.reserved & 1: one thread per edge (reference lookup tallies)
-    bool tiny_work_list = false;   // params.reserved & 2: shrink the work list so the deferred pass is exercised
-    int small_batch_max = 512;     // batches up to this many states take the single-launch kernel (params.reserved & 4 disables)
+    bool fused_mode = false;   // SMPLX_SPACE_FUSED: one thread per edge (reference lookup tallies)
+    int work_list_items = 0;   // > 0: test hook (test_hooks.h) -- a work list this small, so that the deferred pass is exercised
+    int small_batch_max = 512;     // batches up to this many states take the single-launch kernel (SMPLX_SPACE_NO_SMALL_KERNEL disables)
     double small_latency_limit = 70e-6;   // SMPLX_SMALL_KERNEL=always lifts it, =never disables the single-launch kernel
-    bool small_zero_copy = true;
-    bool small_split = false;       // SMPLX_SMALL_SPLIT=1: two waypoint-lane sets per state in the single-launch kernel (measured: waypoint
-                                    // phase 13.4 -> 11.5 us, nothing end to end: the second-half role still does 3/4 of the work)          // SMPLX_SMALL_ZERO_COPY=0: the single-launch kernel with DMA copies instead of host-memory I/O
     DevBuf<unsigned long long> b_counters;
     PinBuf<double> p_q;
     DevBuf<unsigned char> b_out;   // packed outputs of a planner batch (OutView)
@@ -251,47 +247,6 @@ struct smplx_space {
     PinBuf<int32_t> p_ins;
     // speculative successor cache (per state id: evaluated but not yet committed successors)
     struct Rec { int32_t cost; int32_t h; int32_t goal; int32_t known; int32_t prim; };
-    // Child speculation (the space's own batches: smplx_plan on one query, plain GetSuccs).  Under a greedy dive the state
-    // popped next is usually a child of the state just expanded -- a state that did not exist when the batch for its
-    // parent was issued, so nobody could have hinted it.  But its joint values are a pure function of the parent's
-    // (applyMotionPrimitive): the host computes the would-be children of the state that missed with the device's own
-    // arithmetic and lets them ride in the parent's batch as extra rows.  When the parent is committed and a child is
-    // CREATED from its record with bit-identical joint values, the child's evaluated successors are attached to the new
-    // state; if the coordinate already existed (another creator, possibly other joint values) they are dropped.
-    // Measured on config 2 (eps 5, 40 000 expansions): misses 7 693 -> 6 112, but every batch carries ~22 more rows and the
-    // search gets 12 % SLOWER (0.485 -> 0.555 s): this query is not dive-dominated -- most fresh children are created by
-    // expansions that were cache hits, which nothing speculates for.  So: off unless SMPLX_SPEC_CHILDREN=1.
-    bool spec_children = false;
-    // N2 -- expansion continued on the device (rollout rows).  Most misses are on states that were created a moment ago
-    // by an expansion served from the cache: nobody could have hinted them, they did not exist.  So every batch also
-    // evaluates, for its first roll_rows states, the roll_beam best successors (cost + w*h) and, below each, a chain of
-    // best successors roll_depth deep -- rows whose parents are read from the batch's own outputs in HBM (k_small_batch
-    // in rollout mode, one launch per level).  Their records wait in the cache as phantom nodes hanging off the state
-    // they descend from; when that state is committed and the successor is CREATED from the very record the device
-    // continued from (same joint values by construction), the node becomes the new state's cache entry and its own
-    // children move along.  A wrong guess costs GPU rows and host ingest, never results.
-    int roll_depth = 0, roll_beam = 1, roll_rows = 64, roll_w = 5;
-    bool roll_w_fixed = false;               // SMPLX_ROLLOUT_W given: the engine's own search does not set w = eps
-    struct Ph { int64_t rec_off; int32_t cnt, evals, prim, next, child; };
-    std::vector<Ph> ph;
-    std::vector<int32_t> ph_head;            // per id: first phantom child, -1 = none
-    struct RollPlan { int B = 0, R = 0, K = 0, D = 0; int extra() const { return R * K * D; } };
-    RollPlan inflight_roll;
-    int64_t roll_rows_total = 0, roll_attached = 0;
-    int32_t* small_trace = nullptr;          // pinned, 8 ints (SMPLX_DEBUG_TIMING): see SMALL_MARK in kernels.hip
-    double small_trace_sum[6] = {0, 0, 0, 0, 0, 0};
-    int64_t small_trace_n = 0;
-    // SMPLX_DEBUG_TIMING: how old (in expansions) the states are that the search misses on
-    bool dbg_birth_on = false;
-    std::vector<int32_t> dbg_birth;
-    int64_t dbg_age_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int spec_parent = -1;                    // id whose children the last collected batch evaluated
-    int inflight_nspec = 0;                  // extra rows of the batch in flight
-    std::vector<int32_t> spec_prim;          // per extra row: primitive
-    std::vector<double> spec_q;              // per extra row: joint values (N each)
-    size_t spec_first_row = 0;               // collected: where the children's rows sit in the pinned output block (pv)
-    int spec_nrows = 0;
-    int64_t spec_attached = 0, spec_rows = 0;
     std::vector<int64_t> cache_off;     // per id: first record, -1 = not evaluated
     std::vector<int32_t> cache_cnt;
     std::vector<Rec> recs;
@@ -433,7 +388,6 @@ int run_bfs(smplx_space* s, const double xyz[3])
         // blocks per pass: every block of a launch reads the counters even when it has no brick, so a launch of 16 384
         // mostly idle blocks costs ~5 us; in the tail (fewer than 256 bricks flagged) 2 048 do
         int wave_grid_max = 16384;
-        if (const char* e = getenv("SMPLX_BFS_GRID")) wave_grid_max = std::max(64, atoi(e));
         int wave_grid = wave_grid_max;   // (2 048 for the first chunk was tried: the front passes 2 048 bricks by pass 10 -- slower)
         // passes are enqueued in chunks with one look at the counters per chunk: 16 while the front is wide, 4 once fewer
         // than 256 bricks are flagged (the tail of a BFS is a handful of bricks per pass: a look costs about two empty
@@ -466,7 +420,8 @@ int run_bfs(smplx_space* s, const double xyz[3])
             if (pending == 0) break;
             chunk = pending < 256 ? 4 : 16;
             wave_grid = pending < 256 ? std::min(wave_grid_max, 2048) : wave_grid_max;
-            if (pass > 64 * (nbx + nby + nbz) + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
+            // (a label-correcting brick sweep can legitimately need on the order of nbricks passes on maze-like free space)
+            if (pass > 4 * nbricks + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
         }
         s->bfs_levels = pass;
         return SMPLX_OK;
@@ -653,26 +608,22 @@ struct ZeroCopy {
     double* sq = nullptr;
     int32_t* h = nullptr;
     int32_t* id = nullptr;
-    int32_t* sel = nullptr;
 };
 
 bool small_kernel_fits(const smplx_space* s, int B)
 {
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
-    return !s->fused_mode && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && !s->tiny_work_list &&
+    return !s->fused_mode && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && s->work_list_items == 0 &&
            s->pipeline_left == 0;
 }
 
 int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_flags, int32_t* d_coord, double* d_sq,
                   int32_t* d_h, int32_t* d_cost, int32_t* d_lookups, void* d_work, unsigned long long* d_counters,
                   hipStream_t stream, const SmplxSpaceDev* const* stab = nullptr, const unsigned short* state_q = nullptr,
-                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false, const K5Out* k5 = nullptr,
-                  const smplx_space::RollPlan* roll = nullptr, int32_t* d_sel = nullptr)
+                  const ZeroCopy* zero_copy = nullptr, bool force_pipeline = false, const K5Out* k5 = nullptr)
 {
-    // a batch with rollout rows: the caller sized every buffer for B + roll->extra() rows
-    const int Btot = B + (roll ? roll->extra() : 0);
-    ExpandWork k = carve_work(d_work, Btot, s->M);
+    ExpandWork k = carve_work(d_work, B, s->M);
     int32_t* d_id = k5 ? k5->d_id : nullptr;
     SmplxCompactDev cmp;
     std::memset(&cmp, 0, sizeof(cmp));
@@ -680,37 +631,25 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     if (cmp.rec_a) force_pipeline = true;   // the compact stream is produced by k_pipe_finish
     const int32_t* ins_items = k5 && s->d_table ? k5->items : nullptr;
     const int n_ins = ins_items ? k5->n_items : 0;
-    if (s->tiny_work_list) k.capacity = 8 * 16;   // test hook: almost every edge overflows into the deferred pass
+    if (s->work_list_items > 0) k.capacity = s->work_list_items;   // test hook: almost every edge overflows into the deferred pass
     hipEvent_t* ev = nullptr;
     if (s->prof_used + 3 <= s->prof_events.size()) { ev = &s->prof_events[s->prof_used]; s->prof_used += 3; }
     const int bs = blocks_for(B, SMPLX_BLOCK);
     const int be = blocks_for((long long)B * s->M, SMPLX_BLOCK);
     const int64_t* norefs = nullptr;
-    int small_block = smplx_small_block(s->M);
-    size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
-    const int roll_block = small_block;
-    const size_t roll_lds = small_lds;
-    {
-        // a handful of states on per-robot kernels: two waypoint-lane sets per state (kernels.hip k_small_batch); the larger
-        // block holds a CU's LDS almost alone, so not for the batches of hundreds of states of the multi-query driver
-        const int sb = smplx_small_block_split(s->M);
-        const size_t sl = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, sb);
-        if (s->ks.specialized && s->small_split && B <= 64 && sb <= 512 && sl <= 150 * 1024 && small_block <= 512) { small_block = sb; small_lds = sl; }
-    }
-    SmplxRollDev noroll;
-    std::memset(&noroll, 0, sizeof(noroll));
-    noroll.host_sel = s->small_trace;   // -DSMPLX_SMALL_TRACE builds only: phase clock of block 0
+    const int small_block = smplx_small_block(s->M);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     if (!force_pipeline && !s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
-        !s->tiny_work_list && s->pipeline_left == 0) {
+        s->work_list_items == 0 && s->pipeline_left == 0) {
         ++s->small_launches;
         // a handful of states: ONE launch, all FK chains side by side (kernels.hip k_small_batch)
         // zero_copy: parents are read from, and results also written to, that space's pinned host buffers
         const double* qsrc = zero_copy ? zero_copy->q : d_q;
         KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(B + blocks_for(n_ins, small_block)), dim3(small_block), small_lds, stream, s->d_space, qsrc, norefs, B, k.goal_dist,
-                           k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
+                           k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, stab, state_q,
                            zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
                            zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
-                           zero_copy ? zero_copy->id : (int32_t*)nullptr, ins_items, n_ins, noroll);
+                           zero_copy ? zero_copy->id : (int32_t*)nullptr, ins_items, n_ins);
     } else if (s->fused_mode) {
         // one thread walks a whole edge: exact reference early-exit order (and lookup tallies)
         if (d_id) HIP_TRY(hipMemsetAsync(d_id, 0xFF, sizeof(int32_t) * (size_t)B * s->M, stream));   // fused mode: no table lookups
@@ -734,10 +673,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            k.goal_dist, d_flags, d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad,
                            k.work, k.work_count, k.capacity, stab, state_q);
         if (ev) (void)hipEventRecord(ev[0], stream);
-        // (SMPLX_CONFIGS_GRID_X2=1: room for two threads per configuration, kernels.hip const_chain ROLE 1 / 2 -- an experiment)
-        const int grid_x = getenv("SMPLX_CONFIGS_GRID_X2") ? 2 : 1;
         // (a smaller grid was tried -- idle blocks cost next to nothing: 22.0 us at 3 configurations per edge, 21.7 at 1.35)
-        const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK) * grid_x;
+        const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK);
         KLAUNCH(s, K_PIPE_CONFIGS, k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
                            d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, k.work, k.work_count,
                            k.capacity);
@@ -748,43 +685,8 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
                            d_cost, d_lookups, d_counters, k.goal_dist, stab, state_q, d_id, cmp);
         if (ev) (void)hipEventRecord(ev[2], stream);
     }
-    if (roll && roll->extra() > 0 && d_sel) {
-        // N2: one launch per level; level l reads its parents from the rows of level l-1 (level 1: from the real rows)
-        const int RK = roll->R * roll->K;
-        for (int l = 1; l <= roll->D; ++l) {
-            SmplxRollDev rd;
-            rd.on = 1;
-            rd.row0 = B + (l - 1) * RK;
-            rd.base = l == 1 ? 0 : B + (l - 2) * RK;
-            rd.mod = l == 1 ? roll->R : 0;
-            rd.rank_div = l == 1 ? roll->R : 0;
-            rd.w = s->roll_w;
-            rd.out_sel = d_sel;
-            rd.host_sel = zero_copy ? zero_copy->sel : (int32_t*)nullptr;
-            KLAUNCH(s, K_SMALL_BATCH, k_small_batch, dim3(RK), dim3(roll_block), roll_lds, stream, s->d_space, (const double*)d_sq, norefs, Btot,
-                    k.goal_dist, k.state_bad, k.state_lookups, d_flags, d_coord, d_sq, d_h, d_cost, d_lookups, (int*)nullptr, stab, state_q,
-                    zero_copy ? zero_copy->flags : (unsigned char*)nullptr, zero_copy ? zero_copy->coord : (int32_t*)nullptr,
-                    zero_copy ? zero_copy->sq : (double*)nullptr, zero_copy ? zero_copy->h : (int32_t*)nullptr, d_id,
-                    zero_copy ? zero_copy->id : (int32_t*)nullptr, (const int32_t*)nullptr, 0, rd);
-        }
-    }
     HIP_TRY(hipGetLastError());
     return SMPLX_OK;
-}
-
-// N2: how many rollout rows a batch of B states gets (none when the single-launch kernel does not fit this robot)
-smplx_space::RollPlan plan_roll(const smplx_space* s, int B)
-{
-    smplx_space::RollPlan rp;
-    rp.B = B;
-    if (s->roll_depth <= 0 || s->roll_beam <= 0 || s->fused_mode || s->tiny_work_list || !s->prof_events.empty()) return rp;
-    const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
-    if (small_block > 512 || small_lds > 150 * 1024) return rp;
-    rp.R = std::min(B, s->roll_rows);
-    rp.K = s->roll_beam;
-    rp.D = s->roll_depth;
-    return rp;
 }
 
 int reserve_expand(smplx_space* s, int B)
@@ -814,8 +716,6 @@ int new_state(smplx_space* s, const int32_t* coord, const double* q, int32_t h)
     s->done_off.push_back(-1);
     s->done_cnt.push_back(0);
     s->eval_count.push_back(0);
-    s->ph_head.push_back(-1);
-    if (s->dbg_birth_on) s->dbg_birth.push_back((int32_t)s->expansion_log.size());
     s->table.insert(id, s->coords);
     if (s->plain_mode) s->g_est.push_back(1000000000u);
     if (s->d_table) {
@@ -871,7 +771,6 @@ void reset_lattice(smplx_space* s)
     s->start_id = -1;
     s->pending_ins.clear();
     s->table_count = 0;
-    s->spec_parent = -1; s->inflight_nspec = 0; s->spec_nrows = 0;
     if (s->d_table) (void)hipMemsetAsync(s->d_table, 0, s->table_cap * (size_t)s->hs.table.stride * sizeof(int32_t), s->stream);
     // id 0 is reserved for the goal (manip_lattice.cpp:122); it has no coordinate and is never hashed
     s->coords.assign(s->N, 0);
@@ -880,70 +779,6 @@ void reset_lattice(smplx_space* s)
     s->cache_off.push_back(-1); s->cache_cnt.push_back(0);
     s->done_off.push_back(-1); s->done_cnt.push_back(0);
     s->eval_count.push_back(0);
-    s->ph.clear();
-    s->ph_head.assign(1, -1);
-    s->dbg_birth.assign(1, 0);
-    s->inflight_roll = smplx_space::RollPlan();
-}
-
-// host mirrors of the device's mprim_active and applyMotionPrimitive (kernels.hip; manip_lattice_action_space.cpp:662-691,
-// 575-621) -- the same expressions in the same order, compiled with -ffp-contract=off like the kernels
-bool host_mprim_active(const SmplxActionsDev& A, double goal_dist, int type)
-{
-    if (type == SMPLX_MP_LONG) {
-        if (A.use_long_and_short) return true;
-        const bool near_goal = goal_dist <= A.thresh[SMPLX_MP_SHORT];
-        return !(A.enabled[SMPLX_MP_SHORT] && near_goal);
-    } else if (type == SMPLX_MP_SHORT) {
-        if (A.use_long_and_short) return A.enabled[type] != 0;
-        const bool near_goal = goal_dist <= A.thresh[type];
-        return A.enabled[type] && near_goal;
-    }
-    return A.enabled[type] && goal_dist <= A.thresh[type];
-}
-
-void host_apply_prim(const SmplxActionsDev& A, const double* parent, int pi, int nv, double* out)
-{
-    double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
-    if (A.xy_rotate_by_var3 && nv > 3) {
-        double sn, cs;
-        smplx_sincos(parent[3], &sn, &cs);
-        const double a0 = d0, a1 = d1;
-        d0 = cs * a0 + (-sn) * a1;
-        d1 = sn * a0 + cs * a1;
-    }
-    for (int v = 0; v < nv; ++v) {
-        const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
-        out[v] = d + parent[v];
-    }
-}
-
-// the would-be children of state `id` (child speculation, see smplx_space): primitive and joint values of each
-void speculate_children(smplx_space* s, int id)
-{
-    s->spec_prim.clear();
-    s->spec_q.clear();
-    if (!s->spec_children) return;
-    const SmplxActionsDev& A = s->actions.dev;
-    const int N = s->N;
-    // the metric goal distance the device will gate this state's primitives on, as far as the host can tell it from the
-    // state's heuristic (h = cost_per_cell * BFS distance; 32767 = wall or outside); a wrong guess only wastes rows
-    bool know_gd = false;
-    double gd = 0.0;
-    const int32_t h = s->h_of_id[id];
-    const int cpc = s->hs.bfs.cost_per_cell;
-    if (h == 32767) { gd = (double)0x7FFFFFFF * s->grid->res; know_gd = true; }
-    else if (cpc > 0 && h % cpc == 0) { gd = (double)(h / cpc) * s->grid->res; know_gd = true; }
-    const double* parent = &s->qs[(size_t)id * N];
-    for (int pi = 0; pi < s->M; ++pi) {
-        const int type = A.type[pi];
-        if (type != SMPLX_MP_LONG && type != SMPLX_MP_SHORT) continue;
-        if (know_gd && !host_mprim_active(A, gd, type)) continue;
-        s->spec_prim.push_back(pi);
-        const size_t o = s->spec_q.size();
-        s->spec_q.resize(o + N);
-        host_apply_prim(A, parent, pi, N, &s->spec_q[o]);
-    }
 }
 
 // evaluate the successors of `id` plus hinted frontier states in one frontier batch
@@ -1001,7 +836,7 @@ bool takes_small_kernel(const smplx_space* s, int B)
     const int small_block = smplx_small_block(s->M);
     const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     return !s->fused_mode && s->prof_events.empty() && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
-           !s->tiny_work_list && s->pipeline_left == 0;
+           s->work_list_items == 0 && s->pipeline_left == 0;
 }
 
 // enqueue one frontier batch (state `id` plus hinted frontier states) on the space's stream: upload, the
@@ -1011,36 +846,24 @@ int issue_batch(smplx_space* s, int id)
     const int N = s->N, M = s->M;
     const int cap = s->params.batch_states > 0 ? s->params.batch_states : 4096;
     select_batch(s, id, cap);
-    s->spec_parent = -1;   // the rows of the previous batch are about to be overwritten
     std::vector<int32_t>& batch = s->inflight;
-    const int nreal = (int)batch.size();
-    const smplx_space::RollPlan rp = plan_roll(s, nreal);   // N2 rollout rows (they replace host-side child speculation)
-    if (rp.extra() > 0) { s->spec_prim.clear(); s->spec_q.clear(); }
-    else speculate_children(s, id);
-    const int nspec = (int)s->spec_prim.size();
-    s->inflight_nspec = nspec;
-    s->spec_rows += nspec;
-    s->inflight_roll = rp;
-    s->roll_rows_total += rp.extra();
-    const int B = nreal + nspec;
-    const int Btot = B + rp.extra();
-    const size_t BM = (size_t)Btot * M;
-    if (int e = reserve_expand(s, Btot)) return e;
+    const int B = (int)batch.size();
+    const size_t BM = (size_t)B * M;
+    if (int e = reserve_expand(s, B)) return e;
     int e;
     if ((e = s->p_q.reserve((size_t)B * N))) return e;
-    const size_t out_bytes = carve_out(nullptr, BM, N, Btot).bytes;
+    const size_t out_bytes = carve_out(nullptr, BM, N).bytes;
     if ((e = s->b_out.reserve(out_bytes))) return e;
     if ((e = s->p_out.reserve(out_bytes))) return e;
-    s->dv = carve_out(s->b_out.p, BM, N, Btot);
-    s->pv = carve_out(s->p_out.p, BM, N, Btot);
+    s->dv = carve_out(s->b_out.p, BM, N);
+    s->pv = carve_out(s->p_out.p, BM, N);
     auto pack_parents = [&]() {
-        for (int i = 0; i < nreal; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
-        if (nspec) std::memcpy(&s->p_q.p[(size_t)nreal * N], s->spec_q.data(), sizeof(double) * (size_t)nspec * N);
+        for (int i = 0; i < B; ++i) std::memcpy(&s->p_q.p[(size_t)i * N], &s->qs[(size_t)batch[i] * N], sizeof(double) * N);
     };
     pack_parents();
     if (s->pipeline_left > 0 && B <= s->small_batch_max) --s->pipeline_left;   // sitting out on the pipeline path (see smplx_space)
     s->inflight_small = takes_small_kernel(s, B);
-    s->inflight_zero_copy = s->inflight_small && s->small_zero_copy;
+    s->inflight_zero_copy = s->inflight_small;
     s->t_issue = std::chrono::steady_clock::now();
     // K5: the states committed since the last batch join the device table at the head of this batch's first kernel;
     // their (id, coordinate) triples ride in the parents' upload
@@ -1062,9 +885,8 @@ int issue_batch(smplx_space* s, int id)
         k5.items = (const int32_t*)(s->p_q.p + (size_t)B * N);
         ZeroCopy zc;
         zc.q = s->p_q.p; zc.flags = s->pv.flags; zc.coord = s->pv.coord; zc.sq = s->pv.sq; zc.h = s->pv.h; zc.id = s->pv.id;
-        zc.sel = s->pv.sel;
         if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc, false, &k5, &rp, s->dv.sel))) return e;
+                               s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, &zc, false, &k5))) return e;
         HIP_TRY(hipEventRecord(s->batch_done, s->stream));
         ++s->gpu_batches;
         return SMPLX_OK;
@@ -1072,7 +894,7 @@ int issue_batch(smplx_space* s, int id)
     HIP_TRY(hipMemcpyAsync(s->b_q.p, s->p_q.p, sizeof(double) * ((size_t)B * N + item_doubles), hipMemcpyHostToDevice, s->stream));
     k5.items = (const int32_t*)(s->b_q.p + (size_t)B * N);
     if ((e = launch_expand(s, s->b_q.p, B, s->dv.flags, s->dv.coord, s->dv.sq, s->dv.h, s->b_cost.p, s->b_lookups.p,
-                           s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, nullptr, false, &k5, &rp, s->dv.sel))) return e;
+                           s->b_work.p, s->b_counters.p, s->stream, nullptr, nullptr, nullptr, false, &k5))) return e;
     HIP_TRY(hipMemcpyAsync(s->p_out.p, s->b_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));   // one copy for all five outputs
     HIP_TRY(hipEventRecord(s->batch_done, s->stream));
     ++s->gpu_batches;
@@ -1114,42 +936,11 @@ int ingest_row(smplx_space* s, const OutView& pv, size_t row, int* evals_out)
     return cnt;
 }
 
-// N2: the rollout chains below real row `c` of a batch (row index within the whole batch) become phantom nodes of `sid`
-void ingest_rollouts(smplx_space* s, const OutView& pv, const smplx_space::RollPlan& rp, int c, int sid)
-{
-    if (c >= rp.R) return;
-    const int M = s->M, RK = rp.R * rp.K;
-    for (int kb = 0; kb < rp.K; ++kb) {
-        const int chain = kb * rp.R + c;
-        int parent_node = -1;   // -1: the real state
-        size_t want_src = (size_t)c;
-        for (int l = 1; l <= rp.D; ++l) {
-            const size_t row = (size_t)rp.B + (size_t)(l - 1) * RK + chain;
-            const int32_t sel = pv.sel[row];
-            if (sel < 0 || (size_t)(sel / M) != want_src) break;   // nothing to continue from
-            smplx_space::Ph node;
-            node.rec_off = (int64_t)s->recs.size();
-            node.cnt = ingest_row(s, pv, row, &node.evals);
-            node.prim = sel % M;
-            node.child = -1;
-            s->gpu_evals += node.evals;
-            const int idx = (int)s->ph.size();
-            if (parent_node < 0) { node.next = s->ph_head[sid]; s->ph_head[sid] = idx; }
-            else { node.next = s->ph[parent_node].child; s->ph[parent_node].child = idx; }
-            s->ph.push_back(node);
-            parent_node = idx;
-            want_src = row;
-        }
-    }
-}
-
 // the batch in flight has completed: turn its dense outputs into cached successor records
-int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0, const OutView* view = nullptr,
-                  const smplx_space::RollPlan* roll = nullptr)
+int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first = 0, const OutView* view = nullptr)
 {
     if (!src) src = s;   // a cross-query batch lands in the leading space's buffers (or in `view`), at row `first`
     const OutView& pv = view ? *view : src->pv;
-    const int M = s->M;
     const std::vector<int32_t>& batch = s->inflight;
     const int B = (int)batch.size();
     if (src == s && s->inflight_small && s->adaptive_small && B <= 16) {
@@ -1157,14 +948,7 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         // handful-of-states batches are watched: a batch of hundreds of states legitimately takes longer
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_issue).count();
         s->small_latency = s->small_seen == 0 ? dt : 0.8 * s->small_latency + 0.2 * dt;
-        // (every rollout level is one more launch in the batch: 15 us of allowance each)
-        const double limit = s->small_latency_limit + 15e-6 * s->roll_depth;
-        if (++s->small_seen >= 16 && s->small_latency > limit) { s->pipeline_left = 2000; s->small_seen = 0; }
-    }
-    if (src == s && s->inflight_small && s->small_trace && s->small_trace[5] != 0) {
-        for (int k = 1; k < 6; ++k) s->small_trace_sum[k] += (double)(uint32_t)(s->small_trace[k] - s->small_trace[k - 1]) * 0.01;   // us
-        ++s->small_trace_n;
-        s->small_trace[5] = 0;
+        if (++s->small_seen >= 16 && s->small_latency > s->small_latency_limit) { s->pipeline_left = 2000; s->small_seen = 0; }
     }
     if (src == s) { s->inflight_small = false; s->inflight_zero_copy = false; }
     for (int i = 0; i < B; ++i) {
@@ -1175,64 +959,8 @@ int collect_batch(smplx_space* s, const smplx_space* src = nullptr, size_t first
         s->eval_count[sid] = evals;
         s->gpu_evals += evals;
     }
-    // N2: the rollout rows below this query's real rows
-    const smplx_space::RollPlan* rp = roll ? roll : (src == s && !view ? &s->inflight_roll : nullptr);
-    if (rp && rp->extra() > 0)
-        for (int i = 0; i < B; ++i) ingest_rollouts(s, pv, *rp, (int)first + i, batch[i]);
-    if (src == s && !view) s->inflight_roll = smplx_space::RollPlan();
-    // child speculation: the extra rows behind the real states hold the successors of the first state's would-be children.
-    // They are NOT ingested here: the parent is committed right after this (it is the state the search is waiting for),
-    // before another batch can overwrite the pinned output block, and only the rows of children that are really created
-    // get read (attach_speculated_child) -- the other rows cost the host nothing.
-    s->spec_parent = -1;
-    if (src == s && !view && s->inflight_nspec > 0 && B > 0) {
-        s->spec_parent = batch[0];
-        s->spec_first_row = first + (size_t)B;
-        s->spec_nrows = s->inflight_nspec;
-        for (int j = 0; j < s->inflight_nspec; ++j) {   // the evaluation tally only needs the flags
-            int evals = 0;
-            for (int p = 0; p < M; ++p) evals += (pv.flags[(s->spec_first_row + j) * M + p] & SMPLX_F_INACTIVE) ? 0 : 1;
-            s->gpu_evals += evals;
-        }
-    }
-    s->inflight_nspec = 0;
     s->inflight.clear();
     return SMPLX_OK;
-}
-
-// A state has just been CREATED from successor record `prim` of the state whose children were speculated: if the child's
-// joint values are, bit for bit, the ones the host computed for that row, the row's evaluated successors become the new
-// state's cache entry (what a GetSuccs miss on it would have fetched)
-void attach_speculated_child(smplx_space* s, int sid, int prim, const double* q)
-{
-    const int N = s->N, M = s->M;
-    const OutView& pv = s->pv;
-    for (int j = 0; j < s->spec_nrows; ++j) {
-        if (s->spec_prim[j] != prim) continue;
-        if (std::memcmp(&s->spec_q[(size_t)j * N], q, sizeof(double) * N) != 0) return;   // not the values that were evaluated
-        s->cache_off[sid] = (int64_t)s->recs.size();
-        int cnt = 0, evals = 0;
-        for (int p = 0; p < M; ++p) {
-            const size_t k = (s->spec_first_row + (size_t)j) * M + p;
-            const unsigned char f = pv.flags[k];
-            if (!(f & SMPLX_F_INACTIVE)) ++evals;
-            if (!(f & SMPLX_F_VALID)) continue;
-            smplx_space::Rec r;
-            r.cost = s->actions.dev.cost[p];
-            r.h = pv.h[k];
-            r.goal = (f & SMPLX_F_GOAL) ? 1 : 0;
-            r.known = s->d_table ? pv.id[k] : -1;
-            r.prim = p;
-            s->recs.push_back(r);
-            s->rec_coord.insert(s->rec_coord.end(), &pv.coord[k * N], &pv.coord[k * N] + N);
-            s->rec_q.insert(s->rec_q.end(), &pv.sq[k * N], &pv.sq[k * N] + N);
-            ++cnt;
-        }
-        s->cache_cnt[sid] = cnt;
-        s->eval_count[sid] = evals;
-        ++s->spec_attached;
-        return;
-    }
 }
 
 int run_batch(smplx_space* s, int id)
@@ -1277,17 +1005,6 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
             int sid = r.known >= 0 ? r.known : (k < npre ? s->table.find_hashed(c, hashes[k], s->coords) : s->table.find(c, s->coords));
             if (sid < 0) {
                 sid = new_state(s, c, &s->rec_q[(size_t)(off + k) * s->N], r.h);
-                if (s->spec_parent == id) attach_speculated_child(s, sid, r.prim, &s->qs[(size_t)sid * s->N]);
-                // N2: the device continued from exactly this record (same joint values): its rows are the new state's
-                for (int32_t node = s->ph_head[id]; node >= 0; node = s->ph[node].next) {
-                    if (s->ph[node].prim != r.prim) continue;
-                    s->cache_off[sid] = s->ph[node].rec_off;
-                    s->cache_cnt[sid] = s->ph[node].cnt;
-                    s->eval_count[sid] = s->ph[node].evals;
-                    s->ph_head[sid] = s->ph[node].child;
-                    ++s->roll_attached;
-                    break;
-                }
             }
             s->done_succ.push_back(r.goal ? 0 : sid);
             s->done_cost.push_back(r.cost);
@@ -1459,26 +1176,9 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->model = model->hm;
     s->grid = grid;
     s->params = *params;
-    s->fused_mode = (params->reserved & 1) != 0;
-    s->tiny_work_list = (params->reserved & 2) != 0;
-    if (params->reserved & 4) s->small_batch_max = 0;
-    if (const char* e = getenv("SMPLX_SPEC_CHILDREN")) s->spec_children = e[0] != '0';
-    if (const char* e = getenv("SMPLX_SMALL_ZERO_COPY")) s->small_zero_copy = e[0] != '0';
-    if (const char* e = getenv("SMPLX_SMALL_SPLIT")) s->small_split = e[0] != '0';
-    if (const char* e = getenv("SMPLX_SMALL_MAX")) s->small_batch_max = std::max(0, atoi(e));
-    s->dbg_birth_on = getenv("SMPLX_DEBUG_TIMING") != nullptr;
-    if (s->dbg_birth_on && hipHostMalloc((void**)&s->small_trace, 8 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess)
-        std::memset(s->small_trace, 0, 8 * sizeof(int32_t));
-    if (const char* e = getenv("SMPLX_ROLLOUT_DEPTH")) s->roll_depth = std::max(0, std::min(8, atoi(e)));
-    if (const char* e = getenv("SMPLX_ROLLOUT_BEAM")) s->roll_beam = std::max(1, std::min(16, atoi(e)));
-    if (const char* e = getenv("SMPLX_ROLLOUT_ROWS")) s->roll_rows = std::max(1, std::min(4096, atoi(e)));
-    if (const char* e = getenv("SMPLX_ROLLOUT_W")) { s->roll_w = std::max(0, std::min(1000, atoi(e))); s->roll_w_fixed = true; }
-    if (const char* e = getenv("SMPLX_SMALL_KERNEL")) {
-        if (!std::strcmp(e, "always")) s->small_latency_limit = 1.0;
-        else if (!std::strcmp(e, "never")) s->small_batch_max = 0;
-    }
+    s->fused_mode = (params->flags & SMPLX_SPACE_FUSED) != 0;
+    if (params->flags & SMPLX_SPACE_NO_SMALL_KERNEL) s->small_batch_max = 0;
     if (const char* e = getenv("SMPLX_AUTO_SPECULATE")) s->auto_spec = std::max(0, atoi(e));
-    if (const char* e = getenv("SMPLX_AUTO_SPECULATE_W")) s->auto_w = atof(e);
     s->N = s->model.dev.nvars;
     if (!smplx::load_mprim_text(mprim_text, params->resolutions, s->N, s->actions)) {
         const std::string err = s->actions.error;
@@ -1520,7 +1220,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     {
         const char* env = getenv("SMPLX_SPECIALIZE");
         smplx::generic_kernels(s->ks);
-        if (params->reserved & 8) s->specialize_note = "disabled by params.reserved bit 3";
+        if (params->flags & SMPLX_SPACE_GENERIC_KERNELS) s->specialize_note = "disabled by SMPLX_SPACE_GENERIC_KERNELS";
         else if (env && env[0] == '0') s->specialize_note = "disabled by SMPLX_SPECIALIZE=0";
         else if (!smplx::specialized_kernels(s->model.dev, s->ks, s->specialize_note) && env && env[0] == '2') {
             // SMPLX_SPECIALIZE=2: the per-robot build is required
@@ -1588,7 +1288,6 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_brick_queued) (void)hipFree(s->d_brick_queued);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->d_table) (void)hipFree(s->d_table);
-    if (s->small_trace) (void)hipHostFree(s->small_trace);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1598,6 +1297,13 @@ int smplx_space_specialized(const smplx_space* s, char* note, int cap)
     if (!s) return 0;
     if (note && cap > 0) { std::strncpy(note, s->specialize_note.c_str(), cap - 1); note[cap - 1] = 0; }
     return s->ks.specialized ? 1 : 0;
+}
+
+int smplx_test_set_work_list_items(smplx_space* s, int items)
+{
+    if (!s || items < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    s->work_list_items = items / 8 * 8;
+    return SMPLX_OK;
 }
 
 int smplx_space_num_vars(const smplx_space* s) { return s ? s->N : 0; }
@@ -2270,12 +1976,6 @@ struct Search {
                     if (hid > 0 && sp->cache_off[hid] == -1 && sp->done_off[hid] < 0) sp->hint.push_back(hid);
                 }
                 ++sp->cache_misses;
-                if (sp->dbg_birth_on && (size_t)m < sp->dbg_birth.size()) {
-                    const long age = (long)sp->expansion_log.size() - sp->dbg_birth[m];
-                    int b = 0;
-                    for (long a = age; a > 1 && b < 7; a >>= 2) ++b;   // 0-1, 2-7, 8-31, 32-127, ...
-                    ++sp->dbg_age_hist[b];
-                }
                 miss_id = m;
                 if (!defer_issue) {
                     error = issue_batch(sp, m);
@@ -2332,7 +2032,6 @@ struct Search {
                     reorder_open();
                     incons.clear();
                 }
-                if (!sp->roll_w_fixed) sp->roll_w = std::max(1, (int)curr_eps);   // N2: the device ranks children by cost + eps*h too
                 phase = 2;
                 num_before = num;
             }
@@ -2369,7 +2068,6 @@ void fill_search(Search& S, smplx_space* s, const smplx_search_params* p)
     S.max_rep = p->max_expansions;
     S.start_id = s->start_id;
     S.goal_id = 0;
-    if (const char* e = getenv("SMPLX_HINT_SCAN")) S.hint_scan = std::max(1, atoi(e));
 }
 
 }  // namespace
@@ -2535,9 +2233,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                   std::chrono::steady_clock::time_point t0)
 {
     enum { kSets = 8, kInFlight = 4 };
-    int small_zero_copy_max = 512;
-    if (const char* e = getenv("SMPLX_MULTI_SMALL_MAX")) small_zero_copy_max = std::max(0, atoi(e));
-    const bool small_device = getenv("SMPLX_MULTI_SMALL_DEVICE") != nullptr;   // A/B switch: single launch with device buffers + DMA
+    const int small_zero_copy_max = 512;   // batches up to this size: one launch, results written straight to pinned host memory
     smplx_space* lead = spaces[0];
     const int N = lead->N, M = lead->M;
     // one cache line per query state and per counter: the submitter polls them while the workers write them (with the
@@ -2550,8 +2246,7 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
     std::vector<int> set_of(nq, -1);
     std::atomic<int> remaining{nq}, error{0};
     std::string error_msg;
-    int pause_after = 16;   // expansions without a miss before a query hands its worker to the next one (SMPLX_PAUSE_AFTER)
-    if (const char* e = getenv("SMPLX_PAUSE_AFTER")) pause_after = std::max(1, atoi(e));
+    const int pause_after = 16;   // expansions without a miss before a query hands its worker to the next one (measured flat between 4 and 1000)
     for (int q = 0; q < nq; ++q) { qstate(q).store(QS_RUNNABLE); S[q].defer_issue = true; S[q].pause_after = pause_after; }
     {
         std::vector<const SmplxSpaceDev*> tab(nq);
@@ -2562,10 +2257,8 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
     const int cap_q = std::max(16, std::min(512, (lead->params.batch_states > 0 ? lead->params.batch_states : 4096) / std::max(1, nq / 8)));
     const bool dbg = getenv("SMPLX_DEBUG_TIMING") != nullptr;
     const int device = lead->device;
-    int issue_percent = 45;
-    if (const char* e = getenv("SMPLX_ISSUE_PERCENT")) issue_percent = std::max(1, std::min(100, atoi(e)));
-    int groups = 1;   // SMPLX_ISSUE_GROUPS: batches are formed within a group of queries (A/B switch, see the submitter)
-    if (const char* e = getenv("SMPLX_ISSUE_GROUPS")) groups = std::max(1, std::min(8, atoi(e)));
+    const int issue_percent = 45;   // a batch is issued when this share of the live queries waits (1 %: 9.9e5 states/s, 45 %: 1.22e6, 70 %: 1.17e6)
+    const int groups = 1;           // (forming batches within 2-3 independent groups of queries was measured: 1.37-1.39e6 against 1.42e6)
     for (int q = 0; q < nq; ++q) live_cnt[(q / nworkers) % groups].v.fetch_add(1, std::memory_order_relaxed);
     std::vector<BatchBuffers> sets(kSets);
 
@@ -2640,20 +2333,21 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
         long depth_sum = 0;
         auto idle_since = std::chrono::steady_clock::now();
         std::chrono::steady_clock::time_point issued_at[kSets];
-        // SMPLX_DEBUG_TIMELINE: issue / landing times of batches 2000 .. 2059 (us since the first of them)
-        const bool timeline = getenv("SMPLX_DEBUG_TIMELINE") != nullptr;
-        struct Tl { double issue0, issue1, land, prelaunch, postlaunch; int n, depth; };
-        double tl_pre = 0, tl_post = 0;
-        std::vector<Tl> tl;
-        std::vector<int> tl_of_set(kSets, -1);
-        std::chrono::steady_clock::time_point tl0;
+        unsigned poll_spins = 0;
         while (remaining.load(std::memory_order_acquire) > 0 && error.load(std::memory_order_relaxed) == 0) {
             bool did = false;
             // retire landed batches in issue order
             while (in_flight > 0) {
                 BatchBuffers& Bf = sets[oldest];
                 const hipError_t st = hipEventQuery(Bf.done);
-                if (st == hipErrorNotReady) break;
+                if (st == hipErrorNotReady) {
+                    // a batch takes well under a millisecond: one that has not landed after SMPLX_BATCH_TIMEOUT_S is a hung
+                    // kernel; the workers leave through `error` and the call returns (include/smpl_amd.h: every function returns)
+                    if ((++poll_spins & 0x3FFF) == 0 &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - issued_at[oldest]).count() > batch_timeout_seconds())
+                        return set_error(SMPLX_E_HIP, "frontier batch did not complete within SMPLX_BATCH_TIMEOUT_S: kernel hung?");
+                    break;
+                }
                 if (st != hipSuccess) return set_error(SMPLX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
                 Bf.uncollected.store((int)Bf.queries.size(), std::memory_order_relaxed);
                 for (int q : Bf.queries) qstate(q).store(QS_LANDED, std::memory_order_release);
@@ -2662,7 +2356,6 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     const auto nowt = std::chrono::steady_clock::now();
                     lat_sum += std::chrono::duration<double>(nowt - issued_at[oldest]).count();
                     if (in_flight == 1) idle_since = nowt;
-                    if (timeline && tl_of_set[oldest] >= 0) { tl[tl_of_set[oldest]].land = 1e6 * std::chrono::duration<double>(nowt - tl0).count(); tl_of_set[oldest] = -1; }
                 }
                 oldest = (oldest + 1) % kSets;
                 --in_flight;
@@ -2759,7 +2452,6 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                     if (B <= small_zero_copy_max && small_kernel_fits(lead, B) && lead->prof_events.empty()) {
                         // one launch, no copies: parents, query indices and results live in pinned host memory
                         if (dbg) t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
-                        if (timeline) tl_pre = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
                         ZeroCopy zc;
                         zc.q = Nf.p_q.p; zc.flags = Nf.pv.flags; zc.coord = Nf.pv.coord; zc.sq = Nf.pv.sq; zc.h = Nf.pv.h; zc.id = Nf.pv.id;
                         k5.items = (const int32_t*)(Nf.p_q.p + total * N);
@@ -2770,22 +2462,12 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                         HIP_TRY(hipMemcpyAsync(Nf.b_stateq.p, Nf.p_stateq.p, sizeof(unsigned short) * total, hipMemcpyHostToDevice, Nf.stream));
                         k5.items = (const int32_t*)(Nf.b_q.p + total * N);
                         if ((e = launch_expand(lead, Nf.b_q.p, B, Nf.dv.flags, Nf.dv.coord, Nf.dv.sq, Nf.dv.h, Nf.b_cost.p, Nf.b_lookups.p,
-                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, !small_device, &k5))) return e;
+                                               Nf.b_work.p, nullptr, Nf.stream, lead->b_stab.p, Nf.b_stateq.p, nullptr, true, &k5))) return e;
                         HIP_TRY(hipMemcpyAsync(Nf.p_out.p, Nf.b_out.p, out_bytes, hipMemcpyDeviceToHost, Nf.stream));
                     }
-                    if (timeline) tl_post = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
                     HIP_TRY(hipEventRecord(Nf.done, Nf.stream));
-                    if (dbg && timeline && sweeps >= 2000 && sweeps < 2060) {
-                        if (tl.empty()) tl0 = i0;
-                        Tl x;
-                        x.issue0 = 1e6 * std::chrono::duration<double>(i0 - tl0).count();
-                        x.issue1 = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
-                        x.land = -1; x.n = (int)total; x.depth = in_flight; x.prelaunch = tl_pre; x.postlaunch = tl_post;
-                        tl_of_set[next_set] = (int)tl.size();
-                        tl.push_back(x);
-                    }
+                    issued_at[next_set] = i0;
                     if (dbg) {
-                        issued_at[next_set] = i0;
                         depth_sum += in_flight;
                         if (in_flight == 0) t_gpu_idle += std::chrono::duration<double>(i0 - idle_since).count();
                     }
@@ -2807,8 +2489,6 @@ int run_pipelined(smplx_space** spaces, Search* S, int nq, int nworkers, char* d
                                  "issue-to-landing %.1f us on average; %.2f batches already in flight at issue; of the issuing, %.3fs before the launch call\n",
                          sweeps, sweeps ? (double)states / sweeps : 0.0, t_issue, t_gpu_idle, sweeps ? 1e6 * lat_sum / sweeps : 0.0,
                          sweeps ? (double)depth_sum / sweeps : 0.0, t_pack);
-        for (const Tl& x : tl) fprintf(stderr, "[smplx timeline] issue %.0f..%.0f us, landed %.0f us, %d states, %d in flight before; pack %.0f us, launch call %.0f us, record %.0f us\n", x.issue0, x.issue1, x.land, x.n, x.depth,
-                                           x.prelaunch, x.postlaunch - x.prelaunch, (x.issue1 - x.issue0) - x.postlaunch);
         return SMPLX_OK;
     };
 
@@ -2888,12 +2568,6 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         if (nthreads == 1 || nq < 4) {
             worker(0);
             if (rc[0] != SMPLX_OK) return set_error(rc[0], msg[0]);
-        } else if (getenv("SMPLX_MULTI_SLICES")) {
-            // the round-1 scheme, kept for A/B runs: every host thread launches the sweeps of its own slice
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthreads; ++t) th.emplace_back(worker, t);
-            for (auto& x : th) x.join();
-            for (int t = 0; t < nthreads; ++t) if (rc[t] != SMPLX_OK) return set_error(rc[t], msg[t]);
         } else {
             // host_threads worker threads + this thread as the only GPU submitter (run_pipelined)
             if (int e = run_pipelined(spaces, S.data(), nq, std::min(nthreads, nq), done.data(), t_done.data(), t0)) return e;
@@ -2938,21 +2612,8 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
                 t_wait += secs(w0, now());
             }
         }
-        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs; launches: single-kernel %lld pipeline %lld; rollout rows %lld attached %lld\n",
-                         t_resume, t_wait, t_collect, (long long)spaces[0]->small_launches, (long long)spaces[0]->pipe_launches,
-                         (long long)spaces[0]->roll_rows_total, (long long)spaces[0]->roll_attached);
-        if (dbg && spaces[0]->small_trace_n > 0) {
-            const double n = (double)spaces[0]->small_trace_n;
-            const double* t = spaces[0]->small_trace_sum;
-            fprintf(stderr, "[smplx timing] k_small_batch block 0 (us): stage model %.2f, parent %.2f, successors+gate %.2f, waypoints %.2f, verdicts+stores %.2f\n",
-                    t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
-        }
-        if (dbg) {
-            const int64_t* hgm = spaces[0]->dbg_age_hist;
-            fprintf(stderr, "[smplx timing] age (expansions since creation) of the states missed on: 0-1: %lld, 2-7: %lld, 8-31: %lld, 32-127: %lld, "
-                            "128-511: %lld, 512-2047: %lld, more: %lld\n", (long long)hgm[0], (long long)hgm[1], (long long)hgm[2], (long long)hgm[3],
-                    (long long)hgm[4], (long long)hgm[5], (long long)(hgm[6] + hgm[7]));
-        }
+        if (dbg) fprintf(stderr, "[smplx timing] resume(search+issue) %.3fs wait %.3fs collect %.3fs; launches: single-kernel %lld pipeline %lld\n",
+                         t_resume, t_wait, t_collect, (long long)spaces[0]->small_launches, (long long)spaces[0]->pipe_launches);
     }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (wall_seconds) *wall_seconds = wall;

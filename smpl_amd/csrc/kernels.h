@@ -16,8 +16,6 @@
 // small-batch kernel: 7 waypoint lanes per primitive + the state's own lane in whole "config" waves, then one more wave
 // whose lanes are the primitives' bookkeeping lanes + the goal-distance lane (nprims + 1 <= 64)
 static inline int smplx_small_block(int nprims) { return ((nprims * 7 + 1) + 63) / 64 * 64 + 64; }
-// with two waypoint-lane sets per state (k_small_batch: one per half of the trees)
-static inline int smplx_small_block_split(int nprims) { return 2 * (((nprims * 7 + 1) + 63) / 64 * 64) + 64; }
 static inline size_t smplx_lds_bytes_n(size_t blob_bytes, int nroot, int nslots, int nvars, int nthreads)
 {
     return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * nthreads + (size_t)SMPLX_STACK_BYTES * nthreads;
@@ -56,10 +54,10 @@ __global__ void k_pipe_finish(const SmplxSpaceDev* S, const double* Q, const int
                          const SmplxSpaceDev* const* stab, const unsigned short* state_q, int* out_id, SmplxCompactDev cmp);
 __global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int64_t* refs, int B, double* goal_dist_out,
                               unsigned char* state_bad_out, int* state_lookups_out, unsigned char* out_flags, int* out_coord,
-                              double* out_q, int* out_h, int* out_cost, int* out_lookups, int* deferred_count,
+                              double* out_q, int* out_h, int* out_cost, int* out_lookups,
                               const SmplxSpaceDev* const* stab, const unsigned short* state_q, unsigned char* host_flags,
                               int* host_coord, double* host_q, int* host_h, int* out_id, int* host_id, const int* ins_items,
-                              int n_ins, SmplxRollDev roll);
+                              int n_ins);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

@@ -403,8 +403,6 @@ struct ChainState {
     // squared cell distance the lookup returns
     double Tp[12];
     int pd2;
-    // the squared cell distance at every tree's root, looked up in one sweep (const_chain_issue)
-    int pd2s[CM_NT > 0 ? CM_NT : 1];
 };
 
 template <int T_, int K, int KEND>
@@ -473,7 +471,7 @@ __device__ __forceinline__ void apply_joint_const(double q, double T[12])
 // does not clear hands over to the generic traversal at its children (larger child first, as check_tree does), with
 // the link transform kept in C.Tp.  The order of the lookups -- and so the tally, also of a colliding configuration --
 // is unchanged: tree k is resolved before tree k+1 is issued.
-template <int T_, bool Known = false>
+template <int T_>
 __device__ __forceinline__ void issue_root(const SmplxGridDev& g, ChainState& C, int& lookups, double root_p[3])
 {
     constexpr double cx = CM_ROOT_CX[T_], cy = CM_ROOT_CY[T_], cz = CM_ROOT_CZ[T_];
@@ -491,8 +489,7 @@ __device__ __forceinline__ void issue_root(const SmplxGridDev& g, ChainState& C,
 #ifdef ABL_NO_LOOKUP
     C.pd2 = 60000 + (int)(root_p[0] * 0.0);
 #else
-    if constexpr (Known) C.pd2 = C.pd2s[T_];   // second walk: the sweep already fetched it
-    else C.pd2 = grid_d2(g, root_p);
+    C.pd2 = grid_d2(g, root_p);
 #endif
     if constexpr (CM_ROOT_LEFT[T_] >= 0) {
 #pragma unroll
@@ -543,56 +540,11 @@ __device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, con
 }
 
 // PT = the tree whose root lookup was issued at an earlier joint and has not been looked at yet (-1: none)
-// Split of one configuration over two threads of DIFFERENT waves (k_pipe_configs, ROLE 1 and 2; 0 = the whole check):
-// the trees in chain order are cut in two halves.  ROLE 1 walks the chain up to the last tree of the first half and
-// checks those trees against the grid; ROLE 2 walks the whole chain, computes every root position (the checked link
-// pairs need them) but looks up only the trees of the second half, and does the pairs.  Each half is shorter than the
-// whole, and a B = 4096 launch has SIMDs to spare for twice the waves.  A valid configuration's lookup tally is the sum
-// of the two (both add into the same counter); either half can flag the collision.
-// MEASURED (B = 4096, identical results, all parity tests green): 27.3 us against 22.2 us unsplit -- twice the blocks to
-// dispatch and stage, the FK of the first half done twice, and the halves are not the critical path the single-wave
-// picture suggested.  Kept behind -DSMPLX_SPLIT_CONFIGS (SMPLX_RTC_DEFINES) + SMPLX_CONFIGS_GRID_X2=1; off by default.
-constexpr int CM_SPLIT = (CM_NT + 1) / 2;          // trees in the first half
-template <int J>
-constexpr int cm_trees_before()
-{
-    int n = 0;
-    for (int j = 0; j < J && j < CM_NJ; ++j) n += CM_TREE[j] >= 0 ? 1 : 0;
-    return n;
-}
-constexpr int cm_last_joint_of_first_half()
-{
-    int n = 0;
-    for (int j = 0; j < CM_NJ; ++j)
-        if (CM_TREE[j] >= 0 && ++n == CM_SPLIT) return j;
-    return CM_NJ - 1;
-}
-
-// the root position of tree T_ for the link transform in C.T (the expression of issue_root, without the lookup)
-template <int T_>
-__device__ __forceinline__ void root_position(const ChainState& C, double root_p[3])
-{
-    constexpr double cx = CM_ROOT_CX[T_], cy = CM_ROOT_CY[T_], cz = CM_ROOT_CZ[T_];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double acc = 0.0;
-        bool have = false;
-        if constexpr (cx != 0.0) { acc = C.T[4 * i + 0] * cx; have = true; }
-        if constexpr (cy != 0.0) { acc = have ? acc + C.T[4 * i + 1] * cy : C.T[4 * i + 1] * cy; have = true; }
-        if constexpr (cz != 0.0) { acc = have ? acc + C.T[4 * i + 2] * cz : C.T[4 * i + 2] * cz; have = true; }
-        root_p[i] = have ? acc + C.T[4 * i + 3] : C.T[4 * i + 3];
-    }
-}
-
-template <int J, int PT, bool Known = false, int ROLE = 0>
+template <int J, int PT>
 __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                             ChainState& C, int& lookups)
 {
-    if constexpr (ROLE == 1 && J > cm_last_joint_of_first_half()) {
-        // first half: nothing beyond its last tree concerns it
-        if constexpr (PT >= 0) return resolve_root<PT>(M, L, g, C, lookups);
-        else return true;
-    } else if constexpr (J < CM_NJ) {
+    if constexpr (J < CM_NJ) {
         constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J], tree = CM_TREE[J];
         if constexpr (src >= 0) {
 #pragma unroll
@@ -614,24 +566,19 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         }
         if constexpr (tree >= 0) {
             double rp[3];
-            constexpr bool first_half = cm_trees_before<J>() < CM_SPLIT;
-            constexpr bool look = ROLE == 0 || (ROLE == 1 && first_half) || (ROLE == 2 && !first_half);
 #ifdef ABL_NO_TREES
             rp[0] = C.T[3]; rp[1] = C.T[7]; rp[2] = C.T[11];
 #else
-            if constexpr (look) issue_root<tree, Known>(g, C, lookups, rp);
-            else root_position<tree>(C, rp);
+            issue_root<tree>(g, C, lookups, rp);
 #endif
-            if constexpr (ROLE != 1) {
-                constexpr int slot = CM_ROOT_SLOT[tree];
-                if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
+            constexpr int slot = CM_ROOT_SLOT[tree];
+            if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
 #ifndef ABL_NO_PAIRS
-                const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
+            const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
 #endif
-            }
-            return const_chain<J + 1, look ? tree : -1, Known, ROLE>(M, L, g, C, lookups);
+            return const_chain<J + 1, tree>(M, L, g, C, lookups);
         } else {
-            return const_chain<J + 1, -1, Known, ROLE>(M, L, g, C, lookups);
+            return const_chain<J + 1, -1>(M, L, g, C, lookups);
         }
     } else {
         if constexpr (PT >= 0) {
@@ -643,82 +590,6 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         } else {
             return true;
         }
-    }
-}
-
-// ---- the sweep: FK over the whole chain with EVERY tree's root lookup in flight at once ----
-// Walking the chain tree by tree (const_chain) puts one L2/HBM round trip per tree on a wave's critical path -- about
-// 13 dependent gathers per configuration, 61 % of the wave's cycles waiting (rocprofv3, round 1) -- and at B = 4096 there
-// are only ~2 waves per SIMD to hide them behind.  So the chain is walked once WITHOUT looking at any answer: all root
-// positions are computed and all root lookups issued back to back.  Then the answers are read in chain order
-// (const_scan): every root clears -> done, the tally is the number of trees; the first root that fails is a leaf ->
-// collision, the tally is the trees up to it; otherwise some tree has to be descended into, and the chain is walked a
-// second time in the old way (const_chain<.., Known = true>: root answers from registers, descents with the link
-// transform at hand).  Verdict, early-exit point and lookup tally are those of the one-by-one walk.
-template <int J>
-__device__ __forceinline__ void const_chain_issue(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
-                                                  ChainState& C)
-{
-    if constexpr (J < CM_NJ) {
-        constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J], tree = CM_TREE[J];
-        if constexpr (src >= 0) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) C.T[i] = lds_d(L, L.slot_base + 12 * src + i);
-        }
-        double q = 0.0;
-        if constexpr (var >= 0) q = C.q[var];
-        if constexpr (kind >= SMPLX_TK_FIXED_T) apply_joint_const<J, src == SMPLX_SRC_ROOT>(q, C.T);
-        else apply_joint(&M->joints[J], q, C.T, src == SMPLX_SRC_ROOT);
-        if constexpr (save >= 0) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = C.T[i];
-        }
-        if constexpr (tree >= 0) {
-            constexpr double cx = CM_ROOT_CX[tree], cy = CM_ROOT_CY[tree], cz = CM_ROOT_CZ[tree];
-            double rp[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {   // the expression of issue_root
-                double acc = 0.0;
-                bool have = false;
-                if constexpr (cx != 0.0) { acc = C.T[4 * i + 0] * cx; have = true; }
-                if constexpr (cy != 0.0) { acc = have ? acc + C.T[4 * i + 1] * cy : C.T[4 * i + 1] * cy; have = true; }
-                if constexpr (cz != 0.0) { acc = have ? acc + C.T[4 * i + 2] * cz : C.T[4 * i + 2] * cz; have = true; }
-                rp[i] = have ? acc + C.T[4 * i + 3] : C.T[4 * i + 3];
-            }
-            C.pd2s[tree] = grid_d2(g, rp);
-            constexpr int slot = CM_ROOT_SLOT[tree];
-            if constexpr (slot >= 0) { C.roots[3 * slot] = rp[0]; C.roots[3 * slot + 1] = rp[1]; C.roots[3 * slot + 2] = rp[2]; }
-            const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
-        }
-        const_chain_issue<J + 1>(M, L, g, C);
-    }
-}
-
-// trees on joints 0 .. J (inclusive)
-template <int J>
-constexpr int cm_trees_through()
-{
-    int n = 0;
-    for (int j = 0; j <= J && j < CM_NJ; ++j) n += CM_TREE[j] >= 0 ? 1 : 0;
-    return n;
-}
-
-// 1: every root clears; 0: the first root that does not clear is a leaf (collision); 2: a tree has to be descended into
-template <int J>
-__device__ __forceinline__ int const_scan(const ChainState& C, int& tally)
-{
-    if constexpr (J < CM_NJ) {
-        constexpr int tree = CM_TREE[J];
-        if constexpr (tree >= 0) {
-            if (C.pd2s[tree] < CM_ROOT_THR[tree]) {
-                if constexpr (CM_ROOT_LEFT[tree] < 0) { tally = cm_trees_through<J>(); return 0; }
-                else return 2;
-            }
-        }
-        return const_scan<J + 1>(C, tally);
-    } else {
-        tally = cm_trees_through<CM_NJ - 1>();
-        return 1;
     }
 }
 
@@ -840,7 +711,6 @@ __device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, 
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
 // the configuration's joint values are already staged in the thread's LDS slots (stage_config or the caller itself)
-template <int ROLE = 0>
 __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                                     const EdgeRef& e, int& lookups)
 {
@@ -862,24 +732,7 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
         for (int v = 0; v < CM_NV; ++v) C.q[v] = lds_d(L, L.q_base + v);
         C.pair_hit = false; C.recheck_all = false; C.P = P;
         C.pd2 = 0;
-#if !defined(SMPLX_CHAIN_SWEEP) || defined(ABL_NO_TREES) || defined(ABL_NO_LOOKUP)   // measured: the sweep is SLOWER (27.2 vs 23.7 us), see its comment
-        if (!const_chain<0, -1, false, ROLE>(M, L, g, C, lookups)) return false;
-        if constexpr (ROLE == 1) return true;   // the pairs belong to the other half
-#else
-        const_chain_issue<0>(M, L, g, C);
-        int tally = 0;
-        const int verdict = const_scan<0>(C, tally);
-        if (verdict == 0) { lookups += tally; return false; }
-        if (verdict == 1) {
-            lookups += tally;
-        } else {
-            // second walk, with the descents (the pair bookkeeping is redone from scratch: same inputs, same outcome)
-#pragma unroll
-            for (int i = 0; i < 12; ++i) C.T[i] = 0.0;
-            C.pair_hit = false; C.recheck_all = false; C.P = P;
-            if (!const_chain<0, -1, true>(M, L, g, C, lookups)) return false;
-        }
-#endif
+        if (!const_chain<0, -1>(M, L, g, C, lookups)) return false;
         pair_hit = C.pair_hit; recheck_all = C.recheck_all;
         const PendingPairs filled = C.P;
         P = filled;
@@ -970,26 +823,13 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
     return !pair_hit;
 }
 
-template <int ROLE = 0>
 __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                              const EdgeRef& e, int& lookups)
 {
 #ifndef ABL_NO_FK
     stage_config(M, L, e);
 #endif
-    return config_valid_staged<ROLE>(M, L, g, e, lookups);
-}
-
-// role of a waypoint lane (k_small_batch with two lane sets per state): wave-uniform dispatch
-__device__ __forceinline__ bool config_valid_role(int role, const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
-                                                  const EdgeRef& e, int& lookups)
-{
-#if defined(SMPLX_CONST_MODEL) && !defined(SMPLX_CHAIN_SWEEP)
-    if (role == 2) return config_valid<2>(M, L, g, e, lookups);
-    if (role == 1) return config_valid<1>(M, L, g, e, lookups);
-#endif
-    (void)role;
-    return config_valid<0>(M, L, g, e, lookups);
+    return config_valid_staged(M, L, g, e, lookups);
 }
 
 // CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
@@ -1681,18 +1521,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
         pre[k + 1] = pre[k] + c;
     }
     const long long total = (long long)B + pre[SMPLX_WORK_SHARDS];
-#if defined(SMPLX_CONST_MODEL) && !defined(SMPLX_CHAIN_SWEEP) && defined(SMPLX_SPLIT_CONFIGS)
-    // two threads per configuration (const_chain ROLE 1 / 2) when the launch has room for them: the second-half roles take
-    // the first tpad threads, the first-half roles the next tpad, so that every block (and wave) has one role
-    const long long tpad = (total + BLOCK - 1) / BLOCK * BLOCK;
-    const bool split = CM_NT >= 2 && 2 * tpad <= (long long)gridDim.x * BLOCK;
-    if ((long long)blockIdx.x * BLOCK >= (split ? 2 * tpad : total)) return;
-#else
-    const bool split = false;
-    const long long tpad = 0;
-    (void)split; (void)tpad;
     if ((long long)blockIdx.x * BLOCK >= total) return;   // whole block idle: skip staging the model
-#endif
 #ifdef SMPLX_CONST_MODEL
     // Per-robot build: the launch covers every item (engine.hip sizes the grid for B + 3 B M items and k_pipe_setup never
     // lists more), one item per thread.  A block's life is a chain of dependent memory round trips of ~1 us each --
@@ -1702,9 +1531,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     if (total <= (long long)gridDim.x * BLOCK) {
         const int nprims = S->actions.nprims;
         constexpr int nv = CM_NV;
-        const long long i_raw = (long long)blockIdx.x * BLOCK + threadIdx.x;
-        const int role = split ? (i_raw < tpad ? 2 : 1) : 0;      // uniform per block
-        const long long i = role == 1 ? i_raw - tpad : i_raw;
+        const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
         unsigned long long it = SMPLX_WORK_BLANK;
         if (i >= B && i < total) {
             const int li = (int)(i - B);
@@ -1743,16 +1570,9 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             lds_d(L, L.q_base + v) = q;
         }
 #endif
-        bool ok;
-#if !defined(SMPLX_CHAIN_SWEEP) && defined(SMPLX_SPLIT_CONFIGS)
-        if (role == 2) ok = config_valid_staged<2>(M, L, grid, e, lk);
-        else if (role == 1) ok = config_valid_staged<1>(M, L, grid, e, lk);
-        else
-#endif
-            ok = config_valid_staged<0>(M, L, grid, e, lk);
+        const bool ok = config_valid_staged(M, L, grid, e, lk);
         if (is_state) {
-            if (role == 0) state_lookups[i] = lk;
-            else atomicAdd(&state_lookups[i], lk);   // zeroed by k_pipe_setup; the two halves add up
+            state_lookups[i] = lk;
             if (!ok) state_bad[i] = 1;
         } else {
             atomicAdd(&edge_lookups[edge], lk);
@@ -1956,133 +1776,52 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Small frontier batches (a search that misses on a handful of states): ONE launch instead of the four-kernel
-// pipeline, because at this size the cost is launch + dependency latency, not throughput.
-// One block per state; every WAVE has one role, so that no wave runs two long code paths one after the other
-// (round 1 put an edge's 7 waypoint lanes and its bookkeeping lane side by side in one wave):
+// Small frontier batches (a search that misses on a handful of states) and the device-resident search (k_search): ONE
+// block evaluates ONE state, because at this size the cost is launch + dependency latency, not throughput.
+// Every WAVE of the block has one role, so that no wave runs two long code paths one after the other:
 //   config waves   lanes 0 .. 7 M - 1: lane (p, k) checks waypoints k+1, k+8, ... of edge p (an edge with more than
 //                  7 waypoints after the start wraps around its lanes); lane 7 M: the state itself (waypoint 0 of
 //                  every edge).  One configuration per lane, one code path per wave.
 //   last wave      lane p < M: the successor of primitive p -- joint values, limits, coordinates, planning-link FK,
-//                  goal test, heuristic, state-table lookup, and at the end the verdict; lane M: the state's metric goal
-//                  distance (the gate of the primitives).
+//                  goal test, heuristic, and at the end the verdict; lane M: the state's metric goal distance (the gate
+//                  of the primitives).
 // The goal distance is computed first (one lane, while the successor joint values are formed): only the primitives it
-// activates have their waypoints checked.  Results are identical to the pipeline.
+// activates have their waypoints checked -- an ungated snap-to-goal primitive is an edge of a hundred waypoints, 15
+// configurations in sequence on each of its 7 lanes (measured in round 2: 104 us per launch instead of 22).
+// Results are identical to the pipeline.
 // ---------------------------------------------------------------------------------------------
 #define SMPLX_SMALL_LANES 7   // waypoint lanes per edge
 
-// -DSMPLX_SMALL_TRACE (SMPLX_RTC_DEFINES): thread 0 of block 0 leaves the 100 MHz wall clock at each phase boundary in
-// the pinned buffer passed through roll.host_sel (engine.hip prints the averages under SMPLX_DEBUG_TIMING)
-#ifdef SMPLX_SMALL_TRACE
-#define SMALL_MARK(k) do { if (!roll.on && roll.host_sel && blockIdx.x == 0 && threadIdx.x == 0) roll.host_sel[k] = (int)wall_clock64(); } while (0)
-#else
-#define SMALL_MARK(k) do { } while (0)
-#endif
+// what one block-level expansion leaves in LDS (static shared memory of the calling kernel)
+struct ExpandLds {
+    double goal_dist;
+    int state_bad, state_lookups;
+    double parent[SMPLX_MAX_VARS];
+    double sq[SMPLX_MAX_PRIMS][SMPLX_MAX_VARS];   // successor joint values of every primitive
+    int coord[SMPLX_MAX_PRIMS][SMPLX_MAX_VARS];   // defined where flags has the valid bit
+    int edge_bad[SMPLX_MAX_PRIMS], edge_lk[SMPLX_MAX_PRIMS];
+    int h[SMPLX_MAX_PRIMS], lookups[SMPLX_MAX_PRIMS];
+    int flags[SMPLX_MAX_PRIMS];
+};
 
-extern "C" __global__ void __launch_bounds__(512)
-k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
-              double* __restrict__ goal_dist_out, unsigned char* __restrict__ state_bad_out, int* __restrict__ state_lookups_out,
-              unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
-              int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups, int* __restrict__ deferred_count,
-              const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
-              unsigned char* __restrict__ host_flags, int* __restrict__ host_coord, double* __restrict__ host_q,
-              int* __restrict__ host_h, int* __restrict__ out_id, int* __restrict__ host_id,
-              const int* __restrict__ ins_items, int n_ins, SmplxRollDev roll)
+// ManipLattice::GetSuccs loop body (manip_lattice.cpp:254-305) for the state whose joint values sit in X.parent, by all
+// threads of the block (blockDim.x = smplx_small_block(nprims)).  Starts and ends with a barrier: on return X.flags,
+// X.sq, X.coord, X.h, X.lookups, X.goal_dist, X.state_bad and X.state_lookups are final.
+__device__ __forceinline__ void expand_state_block(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxSpaceDev* __restrict__ S,
+                                                   const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid, ExpandLds& X)
 {
-    // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
-    // as a few KB of PCIe stores than as DMA copies); Q may itself be pinned host memory -- the parent's
-    // joint values are staged into LDS once per block
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double s_goal_dist;
-    __shared__ int s_state_bad, s_state_lookups;
-    __shared__ double s_parent[SMPLX_MAX_VARS];
-    __shared__ double s_sq[SMPLX_MAX_PRIMS][SMPLX_MAX_VARS];   // successor joint values of every primitive
-    __shared__ int s_edge_bad[SMPLX_MAX_PRIMS], s_edge_lk[SMPLX_MAX_PRIMS];
-    (void)deferred_count;
-    if (n_ins > 0 && table_insert_block(S, stab, ins_items, n_ins, B)) return;   // K5: see k_pipe_prep
-    SMALL_MARK(0);
-    const int nth = blockDim.x;
-    ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv, nth);
-    SMALL_MARK(1);
-    const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
-    const SmplxGridDev grid = S->grid;
-    // rows: block b of this launch produces row roll.row0 + b of the dense outputs (row0 = 0 outside a rollout)
-    const long long si = (long long)roll.row0 + blockIdx.x;
-    const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
     const SmplxBfsDev bfs = Sq->bfs;
     const int nprims = A.nprims, nv = MV_NVARS(M);
     const int t = threadIdx.x;
     const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
-    const int cfgw = (ncfg + 63) / 64 * 64;
-    // Two lane sets per state when the block was launched with room for them (engine.hip: per-robot build, a handful of
-    // states): every waypoint is checked by two lanes of different waves, one per half of the trees (const_chain ROLE 2
-    // in lanes [0, cfgw), ROLE 1 in [cfgw, 2 cfgw)).  Measured (SMPLX_SMALL_SPLIT=1): the waypoint phase goes from 13.4 to
-    // 11.5 us and the search gains nothing -- the second-half role still walks the whole chain, computes every root
-    // position and does the pairs, three quarters of the work.  Off by default.
-#if defined(SMPLX_CONST_MODEL) && !defined(SMPLX_CHAIN_SWEEP)
-    const bool split = CM_NT >= 2 && (int)blockDim.x >= 2 * cfgw + 64;
-#else
-    const bool split = false;
-#endif
-    const int book0 = split ? 2 * cfgw : cfgw;                // first lane of the bookkeeping wave
-    const int role = split ? (threadIdx.x < cfgw ? 2 : 1) : 0;
-    const int tc = (split && (int)threadIdx.x >= cfgw) ? (int)threadIdx.x - cfgw : (int)threadIdx.x;   // lane within its set
-    long long parent_at = refs ? refs[si] : (int64_t)si;      // where the parent's joint values sit in Q (units of nv)
-    if (roll.on) {
-        // Rollout row (N2: expansion continued on the device): the parent is a SUCCESSOR evaluated by an earlier launch
-        // of this batch -- the (rank+1)-th best valid, non-goal edge of row `src` under cost + w*h (ties: lower
-        // primitive index) -- read from the dense outputs in HBM.  Which edge was taken is written to out_sel; a row
-        // with nothing to continue from marks all its edges inactive.
-        const long long src = (long long)roll.base + (roll.mod > 0 ? (int)(blockIdx.x % (unsigned)roll.mod) : (int)blockIdx.x);
-        const int rank = roll.rank_div > 0 ? (int)(blockIdx.x / (unsigned)roll.rank_div) : 0;
-        __shared__ long long s_key[SMPLX_MAX_PRIMS];
-        __shared__ int s_sel;
-        if (t < nprims) {
-            const unsigned char f = out_flags[src * nprims + t];
-            long long key = -1;
-            if ((f & SMPLX_F_VALID) && !(f & SMPLX_F_GOAL))
-                key = ((long long)A.cost[t] + (long long)roll.w * (long long)out_h[src * nprims + t]) * SMPLX_MAX_PRIMS + t;
-            s_key[t] = key;
-        }
-        __syncthreads();
-        if (t == 0) {
-            long long last = -1;
-            int best = -1;
-            for (int r = 0; r <= rank; ++r) {
-                long long bk = -1;
-                best = -1;
-                for (int p = 0; p < nprims; ++p) {
-                    const long long key = s_key[p];
-                    if (key > last && (bk < 0 || key < bk)) { bk = key; best = p; }
-                }
-                if (best < 0) break;
-                last = bk;
-            }
-            s_sel = best;
-            const int sel = best < 0 ? -1 : (int)(src * nprims + best);
-            roll.out_sel[si] = sel;
-            if (roll.host_sel) roll.host_sel[si] = sel;
-        }
-        __syncthreads();
-        if (s_sel < 0) {
-            if (t < nprims) {
-                out_flags[si * nprims + t] = SMPLX_F_INACTIVE;
-                if (host_flags) host_flags[si * nprims + t] = SMPLX_F_INACTIVE;
-            }
-            return;
-        }
-        parent_at = src * nprims + s_sel;
-    }
-    if (t < nv) s_parent[t] = Q[parent_at * nv + t];
-    if (t < nprims) { s_edge_bad[t] = 0; s_edge_lk[t] = 0; }
-    if (t == 0) { s_state_bad = 0; s_state_lookups = 0; }
+    const int book0 = (ncfg + 63) / 64 * 64;                  // first lane of the bookkeeping wave
+    if (t < nprims) { X.edge_bad[t] = 0; X.edge_lk[t] = 0; }
+    if (t == 0) { X.state_bad = 0; X.state_lookups = 0; }
     __syncthreads();
-    SMALL_MARK(2);
-    const double* parent = s_parent;
+    const double* parent = X.parent;
 
-    // ---- bookkeeping wave, first half: successor joint values of every primitive -> LDS and out_q ----
+    // ---- bookkeeping wave, first half: successor joint values of every primitive -> LDS ----
     const int bp = t - book0;                                 // primitive of a bookkeeping lane
     const bool book = bp >= 0 && bp < nprims;
     int type = 0;
@@ -2092,8 +1831,8 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) have_action = true;
         else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) have_action = true;
         if (have_action) {
-            double* sq = out_q + ((long long)si * nprims + bp) * nv;
             if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+                // applyMotionPrimitive (manip_lattice_action_space.cpp:575-621)
                 double d0 = A.delta[bp][0], d1 = nv > 1 ? A.delta[bp][1] : 0.0;
                 if (A.xy_rotate_by_var3 && nv > 3) {
                     double sn, cs;
@@ -2105,41 +1844,33 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                 MV_UNROLL
                 for (int v = 0; v < nv; ++v) {
                     const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[bp][v]);
-                    const double x = d + parent[v];
-                    s_sq[bp][v] = x;
-                    sq[v] = x;
+                    X.sq[bp][v] = d + parent[v];
                 }
             } else {
                 MV_UNROLL
-                for (int v = 0; v < nv; ++v) { const double x = Sq->goal.angles[v]; s_sq[bp][v] = x; sq[v] = x; }
+                for (int v = 0; v < nv; ++v) X.sq[bp][v] = Sq->goal.angles[v];   // :551-559
             }
         }
     }
     if (bp == nprims) {
-        // ---- metric goal distance of the state (bfs_heuristic.cpp:129-138): the gate of its primitives.  It has to be
-        // known BEFORE the waypoint lanes start: an ungated snap-to-goal primitive is an edge of a hundred waypoints,
-        // 15 configurations in sequence on each of its 7 lanes (measured: 104 us per launch, 25 000 VALU instructions
-        // per state where the pipeline spends 2 500) ----
+        // ---- metric goal distance of the state (bfs_heuristic.cpp:129-138): the gate of its primitives ----
         double pw[3];
         planning_fk(M, parent, pw);
         int c[3];
         world_to_cell(grid, pw, c);
-        const double gd = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
-        s_goal_dist = gd;
-        goal_dist_out[si] = gd;
+        X.goal_dist = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
     }
     __syncthreads();   // every lane of every edge can read its successor's joint values and the gate from LDS
-    SMALL_MARK(3);
 
-    int h = 0, is_goal = 0, early_id = -1, W = 0;
+    int h = 0, is_goal = 0, W = 0;
     bool limits_ok = false;
-    if (t < book0 && tc < ncfg - 1) {
+    if (t < book0 && t < ncfg - 1) {
         // ---- config lanes: one waypoint each ----
-        const int p = tc / SMPLX_SMALL_LANES, slot = tc % SMPLX_SMALL_LANES;
+        const int p = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
         const int ty = A.type[p];
         const bool act = ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
-        if (act && mprim_active(A, s_goal_dist, ty)) {
-            const double* sq = s_sq[p];
+        if (act && mprim_active(A, X.goal_dist, ty)) {
+            const double* sq = X.sq[p];
             if (check_joint_limits(M, sq)) {
                 double motion = 0.0;
                 MV_UNROLL
@@ -2161,24 +1892,24 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                     EdgeRef e;
                     e.start = parent; e.finish = sq;
                     e.alpha = (double)wp * (1.0 / (double)(Wc - 1));
-                    const bool ok = config_valid_role(role, M, L, grid, e, my_lk);
+                    const bool ok = config_valid(M, L, grid, e, my_lk);
                     my_bad = ok ? 0 : 1;
                 }
-                if (my_bad) atomicOr(&s_edge_bad[p], 1);
-                if (my_lk) atomicAdd(&s_edge_lk[p], my_lk);
+                if (my_bad) atomicOr(&X.edge_bad[p], 1);
+                if (my_lk) atomicAdd(&X.edge_lk[p], my_lk);
             }
         }
-    } else if (t < book0 && tc == ncfg - 1) {
+    } else if (t < book0 && t == ncfg - 1) {
         // ---- the state itself: waypoint 0 of each edge (same code path as the other lanes of its wave) ----
         EdgeRef e;
         e.start = parent; e.finish = parent; e.alpha = 0.0;
         int lk = 0;
-        const bool ok = config_valid_role(role, M, L, grid, e, lk);
-        if (!ok) atomicOr(&s_state_bad, 1);
-        if (lk) atomicAdd(&s_state_lookups, lk);
+        const bool ok = config_valid(M, L, grid, e, lk);
+        if (!ok) atomicOr(&X.state_bad, 1);
+        if (lk) atomicAdd(&X.state_lookups, lk);
     } else if (book && have_action) {
         // ---- bookkeeping lane of primitive bp: limits, waypoint count, coordinates, planning-link FK, goal test, heuristic ----
-        const double* sq = s_sq[bp];
+        const double* sq = X.sq[bp];
         limits_ok = check_joint_limits(M, sq);
         if (limits_ok) {
             double motion = 0.0;
@@ -2194,19 +1925,17 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                 W = (int)ceil(motion / 0.05) + 1;
                 if (W < 2) W = 2;
             }
-            int* sc = out_coord + ((long long)si * nprims + bp) * nv;
+            int sc[SMPLX_MAX_VARS];
             MV_UNROLL
-            for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
-            // K5: the table lookup only needs the coordinates: issued here, it lands behind the planning-link FK
-            if (out_id) early_id = table_lookup(Sq->table, sc, nv);
+            for (int v = 0; v < nv; ++v) { sc[v] = var_to_coord(M, v, sq[v]); X.coord[bp][v] = sc[v]; }
             double pw[3];
             planning_fk(M, sq, pw);
-            if (Sq->goal.type == SMPLX_GOAL_JOINT) {
+            if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
                 is_goal = 1;
                 MV_UNROLL
                 for (int v = 0; v < nv; ++v)
                     if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = 0;
-            } else {
+            } else {                                      // XYZ goal :1672-1687
                 is_goal = fabs(pw[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(pw[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
                           fabs(pw[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
             }
@@ -2216,53 +1945,90 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         }
     }
     __syncthreads();   // the waypoint verdicts and the state's own check have landed in LDS
-    SMALL_MARK(4);
 
     // ---- bookkeeping lanes: the verdict of their edge ----
-    if (bp == 0) { state_bad_out[si] = (unsigned char)s_state_bad; state_lookups_out[si] = s_state_lookups; }
     if (book) {
-        const long long eid = (long long)si * nprims + bp;
-        const int* sc = out_coord + eid * nv;
         int flags;
-        int lookups = 0, cost = 0, hh = 0;
-        if (!have_action || !mprim_active(A, s_goal_dist, type)) {
+        int lookups = 0, hh = 0;
+        if (!have_action || !mprim_active(A, X.goal_dist, type)) {
             flags = SMPLX_F_INACTIVE;
         } else if (!limits_ok) {
             flags = SMPLX_F_LIMITS;
         } else {
-            lookups = s_edge_lk[bp] + (W > 0 ? s_state_lookups : 0);
-            const bool ok = (W == 0) || (s_state_bad == 0 && s_edge_bad[bp] == 0);
+            lookups = X.edge_lk[bp] + (W > 0 ? X.state_lookups : 0);
+            const bool ok = (W == 0) || (X.state_bad == 0 && X.edge_bad[bp] == 0);
             if (!ok) {
                 flags = SMPLX_F_COLLISION;
             } else {
                 flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
                 hh = h;
-                cost = A.cost[bp];
             }
         }
+        X.flags[bp] = flags;
+        X.h[bp] = hh;
+        X.lookups[bp] = lookups;
+    }
+    __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(512)
+k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q, const int64_t* __restrict__ refs, int B,
+              double* __restrict__ goal_dist_out, unsigned char* __restrict__ state_bad_out, int* __restrict__ state_lookups_out,
+              unsigned char* __restrict__ out_flags, int* __restrict__ out_coord, double* __restrict__ out_q,
+              int* __restrict__ out_h, int* __restrict__ out_cost, int* __restrict__ out_lookups,
+              const SmplxSpaceDev* const* __restrict__ stab, const unsigned short* __restrict__ state_q,
+              unsigned char* __restrict__ host_flags, int* __restrict__ host_coord, double* __restrict__ host_q,
+              int* __restrict__ host_h, int* __restrict__ out_id, int* __restrict__ host_id,
+              const int* __restrict__ ins_items, int n_ins)
+{
+    // host_*: optional pinned host buffers the results are ALSO written to (zero-copy: a small batch costs less
+    // as a few KB of PCIe stores than as DMA copies); Q may itself be pinned host memory -- the parent's
+    // joint values are staged into LDS once per block
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ ExpandLds X;
+    if (n_ins > 0 && table_insert_block(S, stab, ins_items, n_ins, B)) return;   // K5: see k_pipe_prep
+    ModelLds Mv;
+    ThreadLds L = setup_lds(S, smem, &Mv, blockDim.x);
+    const ModelLds* M = &Mv;
+    const SmplxActionsDev& A = S->actions;
+    const SmplxGridDev grid = S->grid;
+    const long long si = blockIdx.x;
+    const SmplxSpaceDev* Sq = stab ? stab[state_q[si]] : S;
+    const int nprims = A.nprims, nv = MV_NVARS(M);
+    const int t = threadIdx.x;
+    const long long parent_at = refs ? refs[si] : (int64_t)si;      // where the parent's joint values sit in Q (units of nv)
+    if (t < nv) X.parent[t] = Q[parent_at * nv + t];
+    expand_state_block(M, L, S, Sq, grid, X);
+    if (t == 0) { goal_dist_out[si] = X.goal_dist; state_bad_out[si] = (unsigned char)X.state_bad; state_lookups_out[si] = X.state_lookups; }
+    if (t < nprims) {
+        const long long eid = si * nprims + t;
+        const int flags = X.flags[t];
         out_flags[eid] = (unsigned char)flags;
-        out_h[eid] = hh;
-        out_cost[eid] = cost;
-        out_lookups[eid] = lookups;
-        int sid = -1;
-        if (out_id) {   // K5: device copy of the state table (see k_pipe_finish)
-            if (flags & SMPLX_F_VALID) sid = early_id;
-            out_id[eid] = sid;
+        out_h[eid] = X.h[t];
+        out_cost[eid] = (flags & SMPLX_F_VALID) ? A.cost[t] : 0;
+        out_lookups[eid] = X.lookups[t];
+        const bool active = !(flags & SMPLX_F_INACTIVE);
+        if (active) {
+            MV_UNROLL
+            for (int v = 0; v < nv; ++v) out_q[eid * nv + v] = X.sq[t][v];
         }
+        int sid = -1;
+        if (flags & SMPLX_F_VALID) {
+            MV_UNROLL
+            for (int v = 0; v < nv; ++v) out_coord[eid * nv + v] = X.coord[t][v];
+            if (out_id) sid = table_lookup(Sq->table, X.coord[t], nv);   // K5: device copy of the state table (see k_pipe_finish)
+        }
+        if (out_id) out_id[eid] = sid;
         if (host_flags) {
             host_flags[eid] = (unsigned char)flags;
             if (host_id) host_id[eid] = sid;
             if (flags & SMPLX_F_VALID) {
-                host_h[eid] = hh;
+                host_h[eid] = X.h[t];
                 MV_UNROLL
-                for (int v = 0; v < nv; ++v) { host_coord[eid * nv + v] = sc[v]; host_q[eid * nv + v] = s_sq[bp][v]; }
+                for (int v = 0; v < nv; ++v) { host_coord[eid * nv + v] = X.coord[t][v]; host_q[eid * nv + v] = X.sq[t][v]; }
             }
         }
     }
-#ifdef SMPLX_SMALL_TRACE
-    __syncthreads();
-    SMALL_MARK(5);
-#endif
 }
 
 extern "C" __global__ void __launch_bounds__(BLOCK, 2)   // >= 2 waves per SIMD: at most 256 VGPRs, whichever compiler builds it

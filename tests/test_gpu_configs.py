@@ -306,86 +306,6 @@ def test_device_table_on_and_off_give_the_same_search(small_cfg, monkeypatch):
     assert a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"]) and np.array_equal(a["path"], b["path"])
 
 
-def test_child_speculation_switch_gives_the_same_search(small_cfg, monkeypatch):
-    """SMPLX_SPEC_CHILDREN=1: the would-be children of the state that missed ride in its batch (joint values computed on
-    the host with the device's arithmetic) and their evaluated successors are attached when the child is created with
-    bit-identical joint values.  Same search as without, and as the oracle's; and children do get attached."""
-    from oracle_binding import Oracle
-    from smpl_amd import capi
-    _need_gpu()
-    cfg = small_cfg
-    o = Oracle(cfg)
-    o.set_goal_joint(cfg.goal, cfg.goal_tol); o.set_start(cfg.start)
-    o.search_params(5.0, 1.0, 1.0, True, True, 6000, 3000)
-    e = o.plan()
-    misses = {}
-    for env in ("0", "1"):
-        monkeypatch.setenv("SMPLX_SPEC_CHILDREN", env)
-        for no_small in (False, True):
-            s = capi.Space.from_config(cfg, batch_states=256, no_small_kernel=no_small)
-            s.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_start(cfg.start)
-            r = s.plan(5.0, 1.0, 1.0, True, True, 6000, 3000)
-            assert r["cost"] == e["cost"] and np.array_equal(r["expansion_log"], e["expansion_log"]) and np.array_equal(r["path"], e["path"])
-            assert r["committed_succ_evals"] == e["succ_evals"]
-            misses[(env, no_small)] = r["cache_misses"]
-    assert misses[("1", False)] < misses[("0", False)] and misses[("1", True)] < misses[("0", True)]
-
-
-def test_rollout_rows_give_the_same_search(small_cfg, monkeypatch):
-    """N2, SMPLX_ROLLOUT_DEPTH/_BEAM: every batch also evaluates, on the device, the best successors of its states and a
-    chain of best successors below each (parents read from the batch's own outputs in HBM); the rows wait as phantom
-    nodes and become a state's cache entry when the state is created from the very record the device continued from.
-    Same search as without and as the oracle's, fewer misses, behind the single-launch kernel and behind the pipeline."""
-    from oracle_binding import Oracle
-    from smpl_amd import capi
-    _need_gpu()
-    cfg = small_cfg
-    o = Oracle(cfg)
-    o.set_goal_joint(cfg.goal, cfg.goal_tol); o.set_start(cfg.start)
-    o.search_params(5.0, 1.0, 1.0, True, True, 6000, 3000)
-    e = o.plan()
-    misses = {}
-    for depth, beam in ((0, 1), (2, 2), (1, 4)):
-        monkeypatch.setenv("SMPLX_ROLLOUT_DEPTH", str(depth))
-        monkeypatch.setenv("SMPLX_ROLLOUT_BEAM", str(beam))
-        for no_small in (False, True):
-            s = capi.Space.from_config(cfg, batch_states=256, no_small_kernel=no_small)
-            s.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_start(cfg.start)
-            r = s.plan(5.0, 1.0, 1.0, True, True, 6000, 3000)
-            assert r["cost"] == e["cost"] and np.array_equal(r["expansion_log"], e["expansion_log"]) and np.array_equal(r["path"], e["path"])
-            assert r["committed_succ_evals"] == e["succ_evals"]
-            assert s.num_states() == o.num_states()
-            misses[(depth, beam, no_small)] = r["cache_misses"]
-    for no_small in (False, True):
-        assert misses[(2, 2, no_small)] < misses[(0, 1, no_small)] and misses[(1, 4, no_small)] < misses[(0, 1, no_small)]
-
-
-def test_root_lookup_sweep_build_gives_the_same_results(small_cfg, monkeypatch):
-    """-DSMPLX_CHAIN_SWEEP (per-robot build): all tree-root lookups of a configuration in flight at once, answers read in
-    chain order, second walk only where a tree has to be descended into.  Measured slower than the one-by-one walk (so
-    it is not the default) but it must give the same verdicts and the same lookup tallies."""
-    from oracle_binding import Oracle
-    from smpl_amd import capi
-    _need_gpu()
-    cfg = small_cfg
-    monkeypatch.setenv("SMPLX_RTC_DEFINES", "-DSMPLX_CHAIN_SWEEP")
-    s = capi.Space.from_config(cfg, batch_states=256)
-    ok, note = s.specialized()
-    if not ok:
-        pytest.skip("generic kernels in use: the sweep only exists in the per-robot build (" + note + ")")
-    o = Oracle(cfg)
-    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
-    assert o.set_start(cfg.start) == s.set_start(cfg.start)
-    _same_search(o, s, 5.0, 3000, 3000)
-    Q = scenes.random_states(scenes.ARM7_LIMITS, 96, 5)
-    o.set_order(chain=True)
-    _compare_batch(o, s, Q)
-
-
-PR2_RIGHT_ARM_LIMITS = [(-2.1353981634, 0.564601836603), (-0.3536, 1.2963), (-3.75, 0.65), (-2.1213, -0.15),
-                        (-np.pi, np.pi), (-2.0, -0.1), (-np.pi, np.pi)]
-
-
 def test_config3_pr2_right_arm_as_data(cfg3_pr2):
     """SURVEY cfg 3 as specified: the PR2 right arm from data files (the reference's collision_model_pr2.yaml, a URDF
     subset of the arm, the right-arm rows of the demo's allowed-collision matrix) in the 150^3 cluttered-tabletop scene,
@@ -413,12 +333,11 @@ def test_config3_pr2_right_arm_as_data(cfg3_pr2):
     assert go["solved"] == 1 and go["cost"] > 0
 
 
-@pytest.mark.parametrize("env", [{"SMPLX_ISSUE_GROUPS": "2", "SMPLX_ISSUE_PERCENT": "70"}, {"SMPLX_MULTI_SMALL_MAX": "0"},
-                                 {"SMPLX_ISSUE_PERCENT": "1", "SMPLX_SMALL_MAX": "8"}])
-def test_multi_query_driver_switches_do_not_change_results(small_cfg, monkeypatch, env):
-    """The asynchronous driver's scheduling switches (issue groups and threshold, which batches take the single-launch
-    zero-copy kernel) decide WHEN and HOW batches are evaluated, never what a query computes: eight queries through
-    smplx_plan_multi under each setting equal their solo runs."""
+@pytest.mark.parametrize("threads,no_small", [(1, False), (3, False), (3, True), (8, False)])
+def test_multi_query_driver_scheduling_does_not_change_results(small_cfg, monkeypatch, threads, no_small):
+    """How the host-driven multi-query driver schedules its batches (one thread in rounds, worker threads + one GPU
+    submitter, single-launch zero-copy kernel or the four-kernel pipeline) decides WHEN and HOW batches are evaluated,
+    never what a query computes: eight queries through smplx_plan_multi under each setting equal their solo runs."""
     from smpl_amd import capi
     _need_gpu()
     cfg = small_cfg
@@ -432,56 +351,15 @@ def test_multi_query_driver_switches_do_not_change_results(small_cfg, monkeypatc
     def make():
         out = []
         for g in goals:
-            sp = capi.Space(model, grid, cfg.mprim, cfg.params, 512)
+            sp = capi.Space(model, grid, cfg.mprim, cfg.params, 512, no_small_kernel=no_small)
             sp.set_goal_joint(g, cfg.goal_tol); sp.set_start(cfg.start)
             out.append(sp)
         return out
+    monkeypatch.setenv("SMPLX_SEARCH", "host")
     solo = [sp.plan(5.0, 1.0, 1.0, True, True, 3000, 2000) for sp in make()]
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    multi, _ = capi.Space.plan_multi(make(), 5.0, 1.0, 1.0, True, True, 3000, 2000, host_threads=3)
+    multi, _ = capi.Space.plan_multi(make(), 5.0, 1.0, 1.0, True, True, 3000, 2000, host_threads=threads)
     for a, b in zip(solo, multi):
         assert a["solved"] == b["solved"] and a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"])
         assert np.array_equal(a["path"], b["path"]) and a["committed_succ_evals"] == b["committed_succ_evals"]
 
 
-def test_two_threads_per_configuration_build_gives_the_same_results(small_cfg, monkeypatch):
-    """-DSMPLX_SPLIT_CONFIGS + SMPLX_CONFIGS_GRID_X2=1 (an experiment kept as a switch: measured slower): every
-    configuration of the pipeline's collision kernel is checked by two threads of different waves, one per half of the
-    trees; verdicts and the lookup tallies of valid edges must be those of the whole check."""
-    from oracle_binding import Oracle
-    from smpl_amd import capi
-    _need_gpu()
-    cfg = small_cfg
-    monkeypatch.setenv("SMPLX_RTC_DEFINES", "-DSMPLX_SPLIT_CONFIGS")
-    monkeypatch.setenv("SMPLX_CONFIGS_GRID_X2", "1")
-    s = capi.Space.from_config(cfg, batch_states=256, no_small_kernel=True)
-    ok, note = s.specialized()
-    if not ok:
-        pytest.skip("generic kernels in use: the split only exists in the per-robot build (" + note + ")")
-    o = Oracle(cfg)
-    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
-    assert o.set_start(cfg.start) == s.set_start(cfg.start)
-    _same_search(o, s, 5.0, 3000, 3000)
-    Q = scenes.random_states(scenes.ARM7_LIMITS, 300, 6)
-    o.set_order(chain=True)
-    _compare_batch(o, s, Q)
-
-
-def test_single_launch_kernel_with_two_lane_sets_gives_the_same_search(small_cfg, monkeypatch):
-    """SMPLX_SMALL_SPLIT=1 (an experiment kept as a switch): in the single-launch kernel every waypoint is checked by two
-    lanes of different waves, one per half of the trees.  Same search as the oracle's."""
-    from oracle_binding import Oracle
-    from smpl_amd import capi
-    _need_gpu()
-    cfg = small_cfg
-    monkeypatch.setenv("SMPLX_SMALL_SPLIT", "1")
-    monkeypatch.setenv("SMPLX_SMALL_KERNEL", "always")
-    s = capi.Space.from_config(cfg, batch_states=64)
-    o = Oracle(cfg)
-    o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
-    assert o.set_start(cfg.start) == s.set_start(cfg.start)
-    _same_search(o, s, 5.0, 3000, 3000)
-    Q = scenes.random_states(scenes.ARM7_LIMITS, 48, 8)
-    o.set_order(chain=True)
-    _compare_batch(o, s, Q)

@@ -83,27 +83,3 @@ def test_sbpl_shaped_arastar_loop_over_the_plugin_mirror(small_cfg, tmp_path, ep
     cs, cg = o.world_to_grid(*o.planning_fk(cfg.start)), o.world_to_grid(*gp)
     assert ms == cfg.grid.res * float(np.abs(cs.astype(np.int64) - cg).sum())
     assert "done" in lines
-
-
-def test_sbpl_loop_with_rollout_rows_gives_the_same_log(small_cfg, tmp_path):
-    """The hint-free caller (plain GetSuccs) with expansion continued on the device (SMPLX_ROLLOUT_DEPTH / _BEAM): the
-    rollout rows ride in the space's own batches whoever drives it; the log stays the oracle's."""
-    import os
-    from oracle_binding import Oracle
-    cfg = small_cfg
-    exe = build_driver("sbpl_loop_driver", tmp_path)
-    write_query(cfg, tmp_path, [5.0, 1.0, 1.0, 3000, 2000])
-    env = dict(os.environ, SMPLX_ROLLOUT_DEPTH="2", SMPLX_ROLLOUT_BEAM="2")
-    out = subprocess.run([exe, str(tmp_path), "log"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    lines = {l.split(" ", 1)[0]: l.split(" ", 1)[1] if " " in l else "" for l in out.stdout.decode().splitlines()}
-    o = Oracle(cfg)
-    o.set_goal_joint(cfg.goal, cfg.goal_tol)
-    o.set_start(cfg.start)
-    o.search_params(5.0, 1.0, 1.0, True, True, 3000, 2000)
-    e = o.plan()
-    solved, cost, nexp, plen, secs, eps = lines["result"].split()
-    assert int(solved) == e["ok"] and int(nexp) == e["expansions"]
-    assert np.array_equal(np.array(lines["log"].split(), dtype=np.int64), e["expansion_log"])
-    if e["ok"]:
-        assert int(cost) == e["cost"]
