@@ -288,9 +288,27 @@ typedef struct smplx_search_stats {
     int64_t grid_lookups;
 } smplx_search_stats;
 
+/* ARAStar::replan from scratch (arastar.cpp:107-215) on the query of `s`.
+ * Where the search runs.  By default ON THE DEVICE: one persistent workgroup owns the query -- OPEN (the
+ * reference's binary heap with its sift rules, intrusive_heap.hpp:346-395), INCONS, the state table and the search
+ * states live in HBM, the workgroup pops a state, evaluates its successors on its lanes, creates states with ids in its
+ * own commit order (= the reference's ids) and pushes them; the host only launches, enlarges buffers when asked, and
+ * reads results (stats: gpu_batches = kernel launches, cache_misses = 0).  The lattice stays in HBM until an entry point
+ * needs it on the host (smplx_get_state, smplx_expansion_log, smplx_get_succs ...), which then see every state the
+ * device created.  Robots whose expansion does not fit one workgroup's LDS, spaces created with SMPLX_SPACE_FUSED /
+ * SMPLX_SPACE_NO_SMALL_KERNEL, and env SMPLX_SEARCH=host take the host-driven loop instead: the same sequential ARA*
+ * on the host with frontier batches on the GPU (what an external SBPL planner gets through smplx_get_succs).  Results
+ * are identical either way. */
 int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats);
-/* nq independent queries (each its own smplx_space: goal, BFS grid, state table) driven by one host thread on one
- * GPU: a query runs until it misses, its frontier batch is issued on its own stream, and the thread moves on to
+/* diagnostics of the device-resident search of this space: out[0] searches run on the device, [1] buffer enlargements,
+ * [2] pushes of a state already in OPEN in the last search (the reference's INCONS holds a state once per improvement),
+ * [3..9] 10-ns ticks thread 0 of the workgroup spent, last search: select + pop, evaluation (GetSuccs loop body),
+ * getOrCreateState, relaxation + pushes, epsilon steps (reorder), load / store of the launch state; [10] states on the
+ * device, [11] heap entries cached in LDS; [12..15] 0 */
+int smplx_search_counters(const smplx_space* s, int64_t out[16]);
+/* nq independent queries (each its own smplx_space: goal, BFS grid, state table) on one GPU.  Device-resident search
+ * (default): one workgroup per query, all in ONE launch when the queries share grid, robot and primitives.  Host-driven
+ * loop (SMPLX_SEARCH=host): a query runs until it misses, its frontier batch is issued, and the thread moves on to
  * the next query.  No data is exchanged between queries; every query's result equals what smplx_plan gives alone.
  * path_ids holds nq rows of cap ids (may be NULL); stats holds nq entries (seconds = completion time since the
  * start of the call); wall_seconds = duration of the whole call.  Queries created on the same smplx_grid and

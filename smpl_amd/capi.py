@@ -35,6 +35,7 @@ SYMBOLS = [
     "smplx_table_sync", "smplx_compact_rec_b_bytes", "smplx_compact_blocks", "smplx_expand_batch_k5_device", "smplx_expand_batch_k5",
     "smplx_compact_totals_len", "smplx_compact_capacity",
     "smplx_grid_create_empty", "smplx_grid_add_boxes", "smplx_grid_add_points", "smplx_grid_remove_points", "smplx_grid_copy_d2",
+    "smplx_search_counters",
 ]
 
 
@@ -442,6 +443,20 @@ class Space:
         q = np.zeros(self.N); c = np.zeros(self.N, np.int32)
         _chk(lib().smplx_get_state(self.h, i, _p(q, _dp), _p(c, _ip)))
         return q, c
+
+    def search_counters(self):
+        """Diagnostics of the device-resident search (smplx_search_counters)."""
+        out = (C.c_int64 * 16)()
+        lib().smplx_search_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _chk(lib().smplx_search_counters(self.h, out))
+        names = ["searches", "grows", "dup_pushes", "t_idle", "t_select_pop", "t_evaluate", "t_commit", "t_relax", "t_reorder", "t_launch_io",
+                 "device_states", "heap_cache_entries"]
+        return {n: int(out[i]) for i, n in enumerate(names)}
+
+    def set_search_capacity(self, states):
+        """Test hook (csrc/test_hooks.h): first capacity of the device search's buffers."""
+        lib().smplx_test_set_search_capacity.argtypes = [C.c_void_p, C.c_int]
+        _chk(lib().smplx_test_set_search_capacity(self.h, int(states)))
 
     # ---- search ----
     def plan(self, eps0, eps_final, eps_delta, improve=True, bounded=False, max_init=0, max_rep=0, cap=100000):

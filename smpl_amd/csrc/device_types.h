@@ -154,6 +154,8 @@ enum { SMPLX_BH_NJOINTS = 0, SMPLX_BH_NVARS, SMPLX_BH_NTREES, SMPLX_BH_NNODES, S
        SMPLX_BH_OFF_VARI, SMPLX_BH_WORDS = 16 };
 #define SMPLX_MAX_BLOB_BYTES (64 + SMPLX_MAX_JOINTS * 144 + SMPLX_MAX_NODES * 48 + 4096)
 
+struct SmplxSearchDev;
+
 // everything one query needs, resident in HBM
 struct SmplxSpaceDev {
     SmplxModelDev model;
@@ -163,6 +165,60 @@ struct SmplxSpaceDev {
     SmplxActionsDev actions;
     SmplxGoalDev goal;
     SmplxTableDev table;
+    SmplxSearchDev* search;       // device-resident ARA* of this query (null until the first device search)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-resident ARA* (kernels: search_kernel.h, host side: engine.hip).  One persistent workgroup owns one
+// query: OPEN (the reference's intrusive binary heap, intrusive_heap.hpp:346-395), INCONS, the state table, the search
+// states and the committed successor lists all live in HBM (the top of the heap in LDS while the kernel runs); the host
+// only launches, grows buffers when the kernel asks, and reads results.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// search state of one lattice state (ARAStar::SearchState, smpl/include/smpl/search/arastar.h:166-180), 32 bytes = one sector
+struct SmplxSState {
+    uint32_t g, h, f, eg;
+    int32_t bp;
+    int32_t heap_index;           // position in OPEN, 0 = not there (intrusive_heap.hpp:145-166)
+    uint16_t iteration_closed, call_number;
+    uint32_t flags;               // bit 0: pushed into OPEN while already in it (INCONS holds a state once per improvement)
+};
+
+struct SmplxHeapEntry { uint32_t f; int32_t id; };   // f = the state's f (kept equal to it at all times)
+struct SmplxSucc { int32_t id; int32_t cost_prim; };  // cost | primitive << 24 (cost = int(1000 * weight) < 2^24)
+
+// why a launch of k_search came back
+enum { SMPLX_SS_RUNNING = 0,      // step budget of the launch used up: launch again
+       SMPLX_SS_DONE = 1,         // replan finished (solved or not)
+       SMPLX_SS_GROW = 2,         // a buffer is too small for the next expansion: the host enlarges them and launches again
+       SMPLX_SS_ERROR = 3 };
+
+struct SmplxSearchDev {
+    // ---- buffers (HBM) and their capacities
+    int32_t* coord;               // [cap_states][nvars]
+    double* q;                    // [cap_states][nvars]      first creator's joint values (manip_lattice.cpp:1329-1354)
+    SmplxSState* st;              // [cap_states]
+    SmplxHeapEntry* heap;         // [cap_heap + 1], entry 0 unused
+    int32_t* incons;              // [cap_incons]
+    int32_t* log;                 // [cap_log]                expansion log (state ids in pop order)
+    int32_t* done_off;            // [cap_states]             first committed successor, -1 = never expanded
+    int32_t* done_cnt;            // [cap_states]             valid successors | evaluated primitives << 8
+    SmplxSucc* succ;              // [cap_succ]
+    int32_t* path;                // [cap_path]               solution, goal first (bp chain)
+    int32_t cap_states, cap_heap, cap_incons, cap_log, cap_succ, cap_path;
+    // ---- search parameters (smplx_search_params)
+    double initial_eps, final_eps, delta_eps;
+    int32_t improve, bounded, max_init, max_rep;
+    int32_t start_id, pad0;
+    // ---- search state that survives between launches
+    double curr_eps, satisfied_eps;
+    int32_t nstates, heap_size, n_incons, n_log, n_succ, n_path;
+    int32_t iteration, call_number, phase, status;
+    int32_t num, expand_count, expand_count_init, err, solved, cost;
+    int32_t dup_pushes, grow_what;
+    uint32_t goal_f, pad1;
+    int64_t committed_evals, gpu_evals, lookups;
+    int64_t ticks[8];             // 100 MHz wall clock per phase of thread 0: select, pop, evaluate, commit, relax, reorder, idle
 };
 
 // hash of a discretised coordinate (host inserts and device lookups must agree; state ids never depend on it)

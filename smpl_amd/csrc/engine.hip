@@ -188,6 +188,21 @@ struct smplx_model {
     smplx::HostModel hm;
 };
 
+struct DevSearch {
+    unsigned char* arena = nullptr;      // one allocation carved into the buffers of SmplxSearchDev
+    SmplxSearchDev* d_hdr = nullptr;
+    SmplxSearchDev h;                    // host copy of the header: pointers, capacities, and the last state read back
+    struct Caps { int states = 0, heap = 0, incons = 0, log = 0, succ = 0, path = 0; } caps;
+    int dev_states = 0;                  // ids [0, dev_states) exist on the device
+    bool table_fresh = false;            // the device table was just (re)allocated: empty
+    bool host_behind = false;            // the device created states / committed lists the host arrays do not hold yet
+    bool log_on_device = false;          // the expansion log of the last search has not been read back
+    int call_number = 0, n_succ_kept = 0;
+    int64_t grows = 0, searches = 0, ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dup_pushes = 0;
+    int test_capacity = 0;               // test hook: first capacity in states
+};
+
 struct smplx_space {
     smplx::HostModel model;
     const smplx_grid* grid = nullptr;
@@ -199,6 +214,7 @@ struct smplx_space {
     int device = 0;   // HIP device the handle lives on (worker threads select it explicitly)
     int N = 0, M = 0;
     size_t lds_bytes = 0, blob_bytes = 0;
+    int lds_nroot = 0;   // root-position slots per thread in LDS: none in the per-robot build (they live in registers there)
     // BFS
     int32_t* d_bfs = nullptr;
     int32_t* d_queue[2] = {nullptr, nullptr};   // brick lists of the two passes in flight (level mode: the two frontier queues)
@@ -255,7 +271,8 @@ struct smplx_space {
     // committed successor lists (served on re-expansion in later ARA* iterations)
     std::vector<int64_t> done_off;
     std::vector<int32_t> done_cnt;
-    std::vector<int32_t> done_succ, done_cost;
+    std::vector<int32_t> done_succ, done_cost, done_prim;
+    DevSearch ds;                       // device-resident ARA* of this query (search_host.h)
     std::vector<int32_t> hint;
     // Speculation for callers that only know GetSuccs (an unchanged SBPL planner never calls smplx_hint_frontier): the
     // space mirrors the g-values the caller's expansions imply (g[succ] = min(g[succ], g[id] + cost), exactly what
@@ -613,7 +630,7 @@ struct ZeroCopy {
 bool small_kernel_fits(const smplx_space* s, int B)
 {
     const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     return !s->fused_mode && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && s->work_list_items == 0 &&
            s->pipeline_left == 0;
 }
@@ -638,7 +655,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int be = blocks_for((long long)B * s->M, SMPLX_BLOCK);
     const int64_t* norefs = nullptr;
     const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     if (!force_pipeline && !s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
         s->work_list_items == 0 && s->pipeline_left == 0) {
         ++s->small_launches;
@@ -761,7 +778,9 @@ void reset_lattice(smplx_space* s)
 {
     s->coords.clear(); s->qs.clear(); s->h_of_id.clear();
     s->cache_off.clear(); s->cache_cnt.clear(); s->recs.clear(); s->rec_coord.clear(); s->rec_q.clear();
-    s->done_off.clear(); s->done_cnt.clear(); s->done_succ.clear(); s->done_cost.clear();
+    s->done_off.clear(); s->done_cnt.clear(); s->done_succ.clear(); s->done_cost.clear(); s->done_prim.clear();
+    s->ds.dev_states = 0; s->ds.host_behind = false; s->ds.log_on_device = false; s->ds.n_succ_kept = 0;
+    s->ds.table_fresh = s->d_table != nullptr;   // (emptied below)
     s->eval_count.clear();
     s->hint.clear();
     s->pool.clear();
@@ -834,7 +853,7 @@ int wait_event_polling(hipEvent_t ev)
 bool takes_small_kernel(const smplx_space* s, int B)
 {
     const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
     return !s->fused_mode && s->prof_events.empty() && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
            s->work_list_items == 0 && s->pipeline_left == 0;
 }
@@ -1008,6 +1027,7 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
             }
             s->done_succ.push_back(r.goal ? 0 : sid);
             s->done_cost.push_back(r.cost);
+            s->done_prim.push_back(r.prim);
         }
         s->done_off[id] = dof;
         s->done_cnt[id] = cnt;
@@ -1034,6 +1054,26 @@ int get_succs(smplx_space* s, int id, const int32_t** succs, const int32_t** cos
     *costs = s->done_cost.data() + s->done_off[id];
     return SMPLX_OK;
 }
+
+// host mirror of applyMotionPrimitive (kernels.hip; manip_lattice_action_space.cpp:575-621) -- the same expressions in the
+// same order, compiled with -ffp-contract=off like the kernels: bit-identical successor joint values
+void host_apply_prim(const SmplxActionsDev& A, const double* parent, int pi, int nv, double* out)
+{
+    double d0 = A.delta[pi][0], d1 = nv > 1 ? A.delta[pi][1] : 0.0;
+    if (A.xy_rotate_by_var3 && nv > 3) {
+        double sn, cs;
+        smplx_sincos(parent[3], &sn, &cs);
+        const double a0 = d0, a1 = d1;
+        d0 = cs * a0 + (-sn) * a1;
+        d1 = sn * a0 + cs * a1;
+    }
+    for (int v = 0; v < nv; ++v) {
+        const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[pi][v]);
+        out[v] = d + parent[v];
+    }
+}
+
+#include "search_host.h"
 
 }  // namespace
 
@@ -1203,8 +1243,6 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     s->hs.model = s->model.dev;
     s->blob_bytes = smplx::pack_model_blob(s->model.dev, s->hs.model_blob, sizeof(s->hs.model_blob));
     if (s->blob_bytes == 0) { delete s; return set_error(SMPLX_E_LIMIT, "model does not fit the packed LDS image"); }
-    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->model.dev.nroot, s->model.dev.nslots, s->model.dev.nvars);
-    if (s->lds_bytes > 160 * 1024) { delete s; return set_error(SMPLX_E_LIMIT, "model needs more LDS per block than a CU has (160 KB)"); }
     s->hs.grid = grid->dev;
     s->hs.actions = A;
     s->hs.goal.type = SMPLX_GOAL_JOINT;
@@ -1229,6 +1267,9 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
             return set_error(SMPLX_E_HIP, msg);
         }
     }
+    s->lds_nroot = s->ks.specialized ? 0 : s->model.dev.nroot;
+    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars);
+    if (s->lds_bytes > 160 * 1024) { smplx_space_destroy(s); return set_error(SMPLX_E_LIMIT, "model needs more LDS per block than a CU has (160 KB)"); }
     if ((e = hipEventCreateWithFlags(&s->batch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
     const int dx = grid->n[0] + 2, dy = grid->n[1] + 2, dz = grid->n[2] + 2;
@@ -1288,6 +1329,7 @@ void smplx_space_destroy(smplx_space* s)
     if (s->d_brick_queued) (void)hipFree(s->d_brick_queued);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->d_table) (void)hipFree(s->d_table);
+    (void)search_free(s);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1303,6 +1345,47 @@ int smplx_test_set_work_list_items(smplx_space* s, int items)
 {
     if (!s || items < 0) return set_error(SMPLX_E_ARG, "bad argument");
     s->work_list_items = items / 8 * 8;
+    return SMPLX_OK;
+}
+
+int smplx_test_set_search_capacity(smplx_space* s, int states)
+{
+    if (!s || states < 0) return set_error(SMPLX_E_ARG, "bad argument");
+    s->ds.test_capacity = states;
+    return SMPLX_OK;
+}
+
+int smplx_search_counters(const smplx_space* s, int64_t out[16])
+{
+    if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    const DevSearch& D = s->ds;
+    out[0] = D.searches; out[1] = D.grows; out[2] = D.dup_pushes;
+    for (int k = 0; k < 7; ++k) out[3 + k] = D.ticks[k];
+    out[10] = D.h.nstates;
+    out[11] = search_heap_cache_entries(s, nullptr);
+    return SMPLX_OK;
+}
+
+int smplx_test_heap_ops(const int32_t* ops, int nops, int lds_entries, int32_t* top_after)
+{
+    if (!ops || !top_after || nops <= 0 || lds_entries < 1 || lds_entries > 4096) return set_error(SMPLX_E_ARG, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(SMPLX_E_HIP, "no HIP device");
+    DevBuf<int32_t> d_ops, d_top;
+    DevBuf<unsigned long long> d_heap;
+    DevBuf<SmplxSState> d_st;
+    int e;
+    if ((e = d_ops.reserve(2 * (size_t)nops))) return e;
+    if ((e = d_top.reserve((size_t)nops))) return e;
+    if ((e = d_heap.reserve((size_t)nops + 2))) return e;
+    if ((e = d_st.reserve((size_t)nops + 1))) return e;
+    HIP_TRY(hipMemcpy(d_ops.p, ops, sizeof(int32_t) * 2 * (size_t)nops, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_st.p, 0, sizeof(SmplxSState) * ((size_t)nops + 1)));
+    hipLaunchKernelGGL(k_heap_ops, dim3(1), dim3(256), (size_t)lds_entries * 8, 0, d_ops.p, nops, lds_entries, d_heap.p, d_st.p, d_top.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(top_after, d_top.p, sizeof(int32_t) * (size_t)nops, hipMemcpyDeviceToHost));
     return SMPLX_OK;
 }
 
@@ -1723,6 +1806,7 @@ int smplx_set_start(smplx_space* s, const double* q, int* id)
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "set the goal before the start (planner_interface.cpp:1469-1500 order)");
     if (!sane_values(q, s->N)) return set_error(SMPLX_E_ARG, "joint values must be finite (|q| < 1e6)");
     if (!host_check_limits(s->model.dev, q)) return set_error(SMPLX_E_INVALID, "start state violates joint limits");
+    if (int e = pull_lattice(s)) return e;
     uint8_t ok = 0;
     if (int e = smplx_cc_state_valid_batch(s, q, 1, &ok, nullptr)) return e;
     if (!ok) return set_error(SMPLX_E_INVALID, "start state is in collision");
@@ -1745,6 +1829,7 @@ int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int 
 {
     if (!s || !n) return set_error(SMPLX_E_ARG, "null argument");
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+    if (int e = pull_lattice(s)) return e;
     if (!s->plain_mode) {
         // first GetSuccs from outside: start mirroring the caller's g-values (the start has g = 0, arastar.cpp:172-176)
         s->plain_mode = true;
@@ -1770,6 +1855,7 @@ int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int 
 int smplx_hint_frontier(smplx_space* s, const int32_t* ids, int n)
 {
     if (!s || (!ids && n > 0)) return set_error(SMPLX_E_ARG, "null argument");
+    if (int e = pull_lattice(s)) return e;
     s->hint.assign(ids, ids + n);
     return SMPLX_OK;
 }
@@ -1777,24 +1863,32 @@ int smplx_hint_frontier(smplx_space* s, const int32_t* ids, int n)
 int smplx_get_goal_heuristic(smplx_space* s, int id, int32_t* h)
 {
     if (!s || !h) return set_error(SMPLX_E_ARG, "null argument");
+    if (int e = pull_lattice(s)) return e;
     if (id < 0 || id >= (int)s->h_of_id.size()) return set_error(SMPLX_E_STATE, "unknown state id");
     *h = s->h_of_id[id];
     return SMPLX_OK;
 }
 
-int smplx_num_states(const smplx_space* s) { return s ? (int)s->h_of_id.size() : 0; }
+int smplx_num_states(const smplx_space* s)
+{
+    if (!s) return 0;
+    if (s->ds.host_behind) return s->ds.h.nstates;     // the device-resident search created states the host has not fetched yet
+    return (int)s->h_of_id.size();
+}
 
 int smplx_space_counters(const smplx_space* s, int64_t out[6])
 {
     if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
     out[0] = s->gpu_batches; out[1] = s->cache_hits; out[2] = s->cache_misses; out[3] = s->committed_evals;
-    out[4] = s->gpu_evals; out[5] = (int64_t)s->h_of_id.size();
+    out[4] = s->gpu_evals; out[5] = (int64_t)smplx_num_states(s);
     return SMPLX_OK;
 }
 
-int smplx_get_state(const smplx_space* s, int id, double* q, int32_t* coord)
+int smplx_get_state(const smplx_space* cs, int id, double* q, int32_t* coord)
 {
-    if (!s) return set_error(SMPLX_E_ARG, "null argument");
+    if (!cs) return set_error(SMPLX_E_ARG, "null argument");
+    smplx_space* s = const_cast<smplx_space*>(cs);      // (fetching what the device created does not change the lattice)
+    if (int e = pull_lattice(s)) return e;
     if (id < 0 || id >= (int)s->h_of_id.size()) return set_error(SMPLX_E_STATE, "unknown state id");
     if (q) std::memcpy(q, &s->qs[(size_t)id * s->N], sizeof(double) * s->N);
     if (coord) std::memcpy(coord, &s->coords[(size_t)id * s->N], sizeof(int32_t) * s->N);
@@ -2527,6 +2621,8 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         if (!s) return set_error(SMPLX_E_ARG, "null space");
         if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
         if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
+        if (int e = pull_lattice(s)) return e;
+        if (int e = pull_log(s)) return e;
         fill_search(S[q], s, p);
         s->adaptive_small = nq == 1;
         if (nq > 1) s->pipeline_left = 0;
@@ -2552,6 +2648,25 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
                   std::memcmp(&a->hs.actions, &b->hs.actions, sizeof(SmplxActionsDev)) == 0 && a->fused_mode == b->fused_mode;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    // ---- the device-resident search: one persistent workgroup per query, no host round trips.  Taken
+    // whenever the kernel fits the robot (search_host.h); SMPLX_SEARCH=host selects the host-driven loop below, which is
+    // also what serves an external SBPL planner through smplx_get_succs ----
+    {
+        bool device = true;
+        for (int q = 0; q < nq && device; ++q) device = search_on_device(spaces[q]);
+        if (const char* e = getenv("SMPLX_SEARCH"))
+            if (!std::strcmp(e, "device") && !device) return set_error(SMPLX_E_LIMIT, "SMPLX_SEARCH=device: the search kernel does not fit this robot / space");
+        if (device) {
+            if (grouped || nq == 1) {
+                if (int e = search_run(spaces, nq, p, path_ids, cap, stats, t_done.data(), t0)) return e;
+            } else {
+                for (int q = 0; q < nq; ++q)
+                    if (int e = search_run(spaces + q, 1, p, path_ids ? path_ids + (size_t)q * cap : nullptr, cap, stats + q, t_done.data() + q, t0)) return e;
+            }
+            if (wall_seconds) *wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            return SMPLX_OK;
+        }
+    }
     if (grouped) {
         // host threads: each drives a contiguous slice of the queries with its own leading space / stream, so the
         // commit work (hashing, heap, record ingestion) of different slices overlaps; the GPU serves all of them
@@ -2648,11 +2763,17 @@ int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, 
     return smplx_plan_multi(&s, 1, p, path_ids, cap, stats, nullptr, 1);
 }
 
-int smplx_expansion_log_size(const smplx_space* s) { return s ? (int)s->expansion_log.size() : 0; }
-
-int smplx_expansion_log(const smplx_space* s, int32_t* out)
+int smplx_expansion_log_size(const smplx_space* s)
 {
-    if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
+    if (!s) return 0;
+    return s->ds.log_on_device ? s->ds.h.n_log : (int)s->expansion_log.size();
+}
+
+int smplx_expansion_log(const smplx_space* cs, int32_t* out)
+{
+    if (!cs || !out) return set_error(SMPLX_E_ARG, "null argument");
+    smplx_space* s = const_cast<smplx_space*>(cs);
+    if (int e = pull_log(s)) return e;
     std::copy(s->expansion_log.begin(), s->expansion_log.end(), out);
     return SMPLX_OK;
 }
@@ -2660,6 +2781,7 @@ int smplx_expansion_log(const smplx_space* s, int32_t* out)
 int smplx_extract_path(smplx_space* s, const int32_t* ids, int len, double* q)
 {
     if (!s || !ids || !q) return set_error(SMPLX_E_ARG, "null argument");
+    if (int e = pull_lattice(s)) return e;
     // manip_lattice.cpp:2018-2155: every id maps to its stored state; a trailing goal id (0) maps to the
     // cheapest goal-satisfying successor of its predecessor
     for (int i = 0; i < len; ++i) {
@@ -2667,6 +2789,22 @@ int smplx_extract_path(smplx_space* s, const int32_t* ids, int len, double* q)
         if (id == 0) {
             if (i == 0) return set_error(SMPLX_E_STATE, "path cannot start at the goal id");
             const int prev = ids[i - 1];
+            if (prev > 0 && prev < (int)s->cache_off.size() && s->cache_off[prev] < 0 && s->done_off[prev] >= 0 &&
+                s->done_prim.size() == s->done_succ.size()) {
+                // expanded by the device-resident search: the committed list names the primitive of every successor; the
+                // first goal successor in primitive order is the cheapest (every edge costs 1000 here, manip_lattice.cpp:
+                // 1388-1412) and its joint values are recomputed with the device's arithmetic
+                int prim = -1;
+                for (int k = 0; k < s->done_cnt[prev] && prim < 0; ++k)
+                    if (s->done_succ[s->done_off[prev] + k] == 0) prim = s->done_prim[s->done_off[prev] + k];
+                if (prim < 0) return set_error(SMPLX_E_STATE, "no goal successor found during path extraction");
+                const SmplxActionsDev& A = s->actions.dev;
+                if (A.type[prim] == SMPLX_MP_LONG || A.type[prim] == SMPLX_MP_SHORT)
+                    host_apply_prim(A, &s->qs[(size_t)prev * s->N], prim, s->N, q + (size_t)i * s->N);
+                else
+                    std::memcpy(q + (size_t)i * s->N, s->hs.goal.angles, sizeof(double) * s->N);   // snap to a joint goal (:551-559)
+                continue;
+            }
             if (prev <= 0 || prev >= (int)s->cache_off.size() || s->cache_off[prev] < 0)
                 return set_error(SMPLX_E_STATE, "goal predecessor was never expanded");
             int best = -1, best_cost = std::numeric_limits<int>::max();

@@ -10,6 +10,7 @@
 
 #define SMPLX_BLOCK 128          // 2 waves; per-thread LDS scratch keeps ~4 blocks per CU resident
 #define SMPLX_STACK_BYTES 32
+#define SMPLX_SEARCH_STATIC_LDS (20 * 1024)   // static LDS of k_search (ExpandLds + SearchLds + header copy), an upper bound
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
 // dynamic LDS bytes: the packed model, plus (collision kernels) per-thread scratch
@@ -58,6 +59,9 @@ __global__ void k_small_batch(const SmplxSpaceDev* S, const double* Q, const int
                               const SmplxSpaceDev* const* stab, const unsigned short* state_q, unsigned char* host_flags,
                               int* host_coord, double* host_q, int* host_h, int* out_id, int* host_id, const int* ins_items,
                               int n_ins);
+__global__ void k_search(const SmplxSpaceDev* const* stab, int max_steps, int lh, int* status_out);
+__global__ void k_search_table_fill(const SmplxSpaceDev* Sq, const int* coord, int first, int n, int nvars);
+__global__ void k_heap_ops(const int* ops, int nops, int lh, unsigned long long* heap_hbm, SmplxSState* st, int* top_after);
 __global__ void k_edge_valid(const SmplxSpaceDev* S, const double* Aq, const double* Bq, int n, unsigned char* out,
                              int* out_lookups, int* out_waypoints);
 __global__ void k_state_valid(const SmplxSpaceDev* S, const double* Q, int n, unsigned char* out, int* out_lookups);

@@ -1089,10 +1089,15 @@ __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__
     const int* hdr = reinterpret_cast<const int*>(S->model_blob);
     L.nodes = Mv->nodes;
     L.d = (LDS_AS double*)((LDS_AS unsigned char*)smem + hdr[SMPLX_BH_BYTES]);
+#ifdef SMPLX_CONST_MODEL
+    const int nroot = 0;   // per-robot build: the root positions that lead a checked pair live in registers (ChainState::roots)
+#else
+    const int nroot = Mv->nroot;
+#endif
     L.root_base = 0;
-    L.slot_base = 3 * Mv->nroot;
-    L.q_base = 3 * Mv->nroot + 12 * Mv->nslots;
-    const int nd = 3 * Mv->nroot + 12 * Mv->nslots + Mv->nvars;
+    L.slot_base = 3 * nroot;
+    L.q_base = 3 * nroot + 12 * Mv->nslots;
+    const int nd = 3 * nroot + 12 * Mv->nslots + Mv->nvars;
     L.stk = (LDS_AS unsigned char*)(L.d + nd * nthreads);
     __syncthreads();
     return L;
@@ -2548,3 +2553,5 @@ k_bfs_brick_seed(int* __restrict__ dist, size_t origin, int brick, int* __restri
         }
     }
 }
+
+#include "search_kernel.h"

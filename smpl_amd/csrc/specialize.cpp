@@ -29,7 +29,7 @@ namespace {
 
 const char* const kNames[K_COUNT] = {"k_state_prep", "k_expand", "k_pipe_prep", "k_pipe_setup", "k_pipe_configs",
                                      "k_pipe_finish", "k_small_batch", "k_edge_valid", "k_state_valid", "k_heuristic",
-                                     "k_sphere_positions"};
+                                     "k_sphere_positions", "k_search"};
 
 uint64_t fnv1a(uint64_t h, const std::string& s)
 {
@@ -141,7 +141,7 @@ void generic_kernels(KernelSet& ks)
     const void* g[K_COUNT] = {(const void*)k_state_prep, (const void*)k_expand, (const void*)k_pipe_prep,
                               (const void*)k_pipe_setup, (const void*)k_pipe_configs, (const void*)k_pipe_finish,
                               (const void*)k_small_batch, (const void*)k_edge_valid, (const void*)k_state_valid,
-                              (const void*)k_heuristic, (const void*)k_sphere_positions};
+                              (const void*)k_heuristic, (const void*)k_sphere_positions, (const void*)k_search};
     for (int i = 0; i < K_COUNT; ++i) { ks.k[i].fn = nullptr; ks.k[i].generic = g[i]; }
     ks.specialized = false;
 }
@@ -156,6 +156,7 @@ bool specialized_kernels(const SmplxModelDev& model, KernelSet& ks, std::string&
     h = fnv1a(h, SRC_DET_MATH_H);
     h = fnv1a(h, SRC_DEVICE_TYPES_H);
     h = fnv1a(h, SRC_KERNELS_H);
+    h = fnv1a(h, SRC_SEARCH_KERNEL_H);
     for (const char* o : kRtcOptions) h = fnv1a(h, o);
     for (const std::string& x : rtc_extra_defines()) h = fnv1a(h, x);
     int major = 0, minor = 0;

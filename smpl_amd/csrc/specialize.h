@@ -18,7 +18,7 @@ namespace smplx {
 
 enum KernelId {
     K_STATE_PREP = 0, K_EXPAND, K_PIPE_PREP, K_PIPE_SETUP, K_PIPE_CONFIGS, K_PIPE_FINISH, K_SMALL_BATCH, K_EDGE_VALID,
-    K_STATE_VALID, K_HEURISTIC, K_SPHERE_POSITIONS, K_COUNT
+    K_STATE_VALID, K_HEURISTIC, K_SPHERE_POSITIONS, K_SEARCH, K_COUNT
 };
 
 // a kernel to launch: the per-robot build (hipFunction_t from the hiprtc module) when present, else the generic

@@ -13,6 +13,15 @@ extern "C" {
  * 0 restores the default size. */
 int smplx_test_set_work_list_items(smplx_space* s, int items);
 
+/* The heap primitives of the device-resident search (search_kernel.h) driven by an op sequence in the language of
+ * oracle/heap_ref_driver.cpp (pairs code, key; see k_heap_ops): top_after[i] = element at the top after op i, -1 when empty.
+ * lds_entries = how many leading heap entries live in LDS (the rest in HBM), 1 .. 4096. */
+int smplx_test_heap_ops(const int32_t* ops, int nops, int lds_entries, int32_t* top_after);
+
+/* First capacity (states) of the device-resident search's buffers, so that a test can make a search outgrow them
+ * (SMPLX_SS_GROW: the host enlarges and launches again); 0 restores the default sizing. */
+int smplx_test_set_search_capacity(smplx_space* s, int states);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,6 +295,7 @@ def test_device_table_on_and_off_give_the_same_search(small_cfg, monkeypatch):
     _need_gpu()
     cfg = small_cfg
     runs = []
+    monkeypatch.setenv("SMPLX_SEARCH", "host")      # (the device-resident search always keeps the table on the device)
     for env in ("1", "0"):
         monkeypatch.setenv("SMPLX_DEVICE_TABLE", env)
         s = capi.Space.from_config(cfg, batch_states=512)
@@ -304,6 +305,10 @@ def test_device_table_on_and_off_give_the_same_search(small_cfg, monkeypatch):
     (a, na), (b, nb) = runs
     assert na == nb and na > (1 << 17)                      # more states than half the initial 2^18 slots: it grew
     assert a["cost"] == b["cost"] and np.array_equal(a["expansion_log"], b["expansion_log"]) and np.array_equal(a["path"], b["path"])
+
+
+PR2_RIGHT_ARM_LIMITS = [(-2.1353981634, 0.564601836603), (-0.3536, 1.2963), (-3.75, 0.65), (-2.1213, -0.15),
+                        (-np.pi, np.pi), (-2.0, -0.1), (-np.pi, np.pi)]
 
 
 def test_config3_pr2_right_arm_as_data(cfg3_pr2):

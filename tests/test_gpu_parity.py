@@ -183,12 +183,16 @@ def test_getsuccs_ids_match_sequential_reference_order(ctx):
 
 
 @pytest.mark.parametrize("semantics", ["fork", "upstream"])
-@pytest.mark.parametrize("fused", [False, True, "pipeline-only"])
+@pytest.mark.parametrize("fused", [False, True, "pipeline-only", "host-loop"])
 @pytest.mark.parametrize("goal_kind", ["joint", "xyz"])
-def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused, semantics):
+def test_arastar_expansion_order_and_cost(small_cfg, goal_kind, fused, semantics, monkeypatch):
+    """fused False: the default path (device-resident search); True / pipeline-only / host-loop: the host-driven ARA* with
+    the fused kernels, the four-kernel pipeline for every batch, the default kernels."""
     from oracle_binding import Oracle
     from smpl_amd import capi
     cfg = small_cfg
+    if fused == "host-loop":
+        monkeypatch.setenv("SMPLX_SEARCH", "host")
     rot = semantics == "fork"
     o = Oracle(cfg, xy_rotate=rot)
     s = capi.Space.from_config(cfg, batch_states=256, xy_rotate=rot, fused=(fused is True),
