@@ -1809,11 +1809,19 @@ struct ExpandLds {
     int flags[SMPLX_MAX_PRIMS];
 };
 
-// ManipLattice::GetSuccs loop body (manip_lattice.cpp:254-305) for the state whose joint values sit in X.parent, by all
-// threads of the block (blockDim.x = smplx_small_block(nprims)).  Starts and ends with a barrier: on return X.flags,
-// X.sq, X.coord, X.h, X.lookups, X.goal_dist, X.state_bad and X.state_lookups are final.
+// lanes of ONE wave exchange data through LDS: no block barrier needed, only that neither the compiler nor the memory
+// pipeline reorders the accesses (LDS operations of a wave execute in order)
+#define SMPLX_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// ManipLattice::GetSuccs loop body (manip_lattice.cpp:254-305) for the state whose joint values are at parent_src (HBM or
+// pinned host memory), by all threads of the block (blockDim.x = smplx_small_block(nprims)).  The bookkeeping wave loads
+// the parent itself and starts at once; the other waves join at the first of three barriers (a caller may let them arrive
+// late: k_search sifts its heap meanwhile).  Ends with a barrier: on return X.parent, X.flags, X.sq, X.coord, X.h, X.lookups,
+// X.goal_dist, X.state_bad and X.state_lookups are final.
 __device__ __forceinline__ void expand_state_block(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxSpaceDev* __restrict__ S,
-                                                   const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid, ExpandLds& X)
+                                                   const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid, ExpandLds& X,
+                                                   const double* __restrict__ parent_src)
 {
     const SmplxActionsDev& A = S->actions;
     const SmplxBfsDev bfs = Sq->bfs;
@@ -1823,12 +1831,15 @@ __device__ __forceinline__ void expand_state_block(const ModelLds* __restrict__ 
     const int book0 = (ncfg + 63) / 64 * 64;                  // first lane of the bookkeeping wave
     if (t < nprims) { X.edge_bad[t] = 0; X.edge_lk[t] = 0; }
     if (t == 0) { X.state_bad = 0; X.state_lookups = 0; }
-    __syncthreads();
     const double* parent = X.parent;
 
-    // ---- bookkeeping wave, first half: successor joint values of every primitive -> LDS ----
+    // ---- bookkeeping wave, first half: the parent's joint values, then the successor joint values of every primitive -> LDS ----
     const int bp = t - book0;                                 // primitive of a bookkeeping lane
     const bool book = bp >= 0 && bp < nprims;
+    if (bp >= 0) {
+        if (bp < nv) X.parent[bp] = parent_src[bp];
+        SMPLX_WAVE_SYNC();
+    }
     int type = 0;
     bool have_action = false;
     if (book) {
@@ -2002,8 +2013,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     const int nprims = A.nprims, nv = MV_NVARS(M);
     const int t = threadIdx.x;
     const long long parent_at = refs ? refs[si] : (int64_t)si;      // where the parent's joint values sit in Q (units of nv)
-    if (t < nv) X.parent[t] = Q[parent_at * nv + t];
-    expand_state_block(M, L, S, Sq, grid, X);
+    expand_state_block(M, L, S, Sq, grid, X, Q + parent_at * nv);
     if (t == 0) { goal_dist_out[si] = X.goal_dist; state_bad_out[si] = (unsigned char)X.state_bad; state_lookups_out[si] = X.state_lookups; }
     if (t < nprims) {
         const long long eid = si * nprims + t;
