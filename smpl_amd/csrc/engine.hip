@@ -1382,7 +1382,7 @@ int smplx_test_heap_ops(const int32_t* ops, int nops, int lds_entries, int32_t* 
     if ((e = d_st.reserve((size_t)nops + 1))) return e;
     HIP_TRY(hipMemcpy(d_ops.p, ops, sizeof(int32_t) * 2 * (size_t)nops, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_st.p, 0, sizeof(SmplxSState) * ((size_t)nops + 1)));
-    hipLaunchKernelGGL(k_heap_ops, dim3(1), dim3(256), (size_t)lds_entries * 8, 0, d_ops.p, nops, lds_entries, d_heap.p, d_st.p, d_top.p);
+    hipLaunchKernelGGL(k_heap_ops, dim3(1), dim3(64), (size_t)lds_entries * 8, 0, d_ops.p, nops, lds_entries, d_heap.p, d_st.p, d_top.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(top_after, d_top.p, sizeof(int32_t) * (size_t)nops, hipMemcpyDeviceToHost));

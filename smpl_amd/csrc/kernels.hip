@@ -1809,16 +1809,176 @@ struct ExpandLds {
     int flags[SMPLX_MAX_PRIMS];
 };
 
+// ---- the GetSuccs loop body (manip_lattice.cpp:254-305) in lane-sized pieces; expand_state_block (k_small_batch) and
+// k_search (search_kernel.h) put them together around their own barriers ----
+
+// can the primitive produce an action at all (a snap needs a joint-space goal: manip_lattice_action_space.cpp:551-559)
+__device__ __forceinline__ bool prim_has_action(const SmplxActionsDev& A, const SmplxSpaceDev* __restrict__ Sq, int p)
+{
+    const int ty = A.type[p];
+    return ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
+}
+
+// bookkeeping lane of primitive p, first half: the successor's joint values -> X.sq[p] (applyMotionPrimitive,
+// manip_lattice_action_space.cpp:575-621)
+__device__ __forceinline__ void expand_successor_values(const ModelLds* __restrict__ M, const SmplxActionsDev& A,
+                                                        const SmplxSpaceDev* __restrict__ Sq, ExpandLds& X, int p)
+{
+    const int nv = MV_NVARS(M);
+    const double* parent = X.parent;
+    const int type = A.type[p];
+    if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
+        double d0 = A.delta[p][0], d1 = nv > 1 ? A.delta[p][1] : 0.0;
+        if (A.xy_rotate_by_var3 && nv > 3) {
+            double sn, cs;
+            smplx_sincos(parent[3], &sn, &cs);
+            const double a0 = d0, a1 = d1;
+            d0 = cs * a0 + (-sn) * a1;
+            d1 = sn * a0 + cs * a1;
+        }
+        MV_UNROLL
+        for (int v = 0; v < nv; ++v) {
+            const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[p][v]);
+            X.sq[p][v] = d + parent[v];
+        }
+    } else {
+        MV_UNROLL
+        for (int v = 0; v < nv; ++v) X.sq[p][v] = Sq->goal.angles[v];   // :551-559
+    }
+}
+
+// metric goal distance of the state in X.parent (bfs_heuristic.cpp:129-138): the gate of its primitives
+__device__ __forceinline__ double expand_goal_distance(const ModelLds* __restrict__ M, const SmplxGridDev& grid, const SmplxBfsDev& bfs,
+                                                       const ExpandLds& X)
+{
+    double pw[3];
+    planning_fk(M, X.parent, pw);
+    int c[3];
+    world_to_cell(grid, pw, c);
+    return !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
+}
+
+// waypoint count of the edge parent -> sq (robot_motion_collision_model.cpp:371-407, .h:352-366, 173-181)
+__device__ __forceinline__ int expand_waypoint_count(const ModelLds* __restrict__ M, const double* parent, const double* sq)
+{
+    const int nv = MV_NVARS(M);
+    double motion = 0.0;
+    MV_UNROLL
+    for (int v = 0; v < nv; ++v) {
+        const int vt = MV_TYPE(M, v);
+        const double sv = parent[v], fv = sq[v];
+        if (vt == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
+        else if (vt == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
+        else if (vt == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
+    }
+    int W = 0;
+    if (motion != 0.0) {
+        W = (int)ceil(motion / 0.05) + 1;
+        if (W < 2) W = 2;
+    }
+    return W;
+}
+
+// config lane c of the block: c < ncfg - 1: lane (p, slot) checks waypoints slot+1, slot+8, ... of edge p (an edge longer
+// than 7 waypoints wraps around its lanes); c == ncfg - 1: the state itself (waypoint 0 of every edge)
+__device__ __forceinline__ void expand_config_lane(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxActionsDev& A,
+                                                   const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid, ExpandLds& X, int c, int ncfg)
+{
+    const double* parent = X.parent;
+    if (c < ncfg - 1) {
+        const int p = c / SMPLX_SMALL_LANES, slot = c % SMPLX_SMALL_LANES;
+        if (prim_has_action(A, Sq, p) && mprim_active(A, X.goal_dist, A.type[p])) {
+            const double* sq = X.sq[p];
+            if (check_joint_limits(M, sq)) {
+                const int Wc = expand_waypoint_count(M, parent, sq);
+                int my_bad = 0, my_lk = 0;
+                for (int wp = slot + 1; wp < Wc && !my_bad; wp += SMPLX_SMALL_LANES) {
+                    EdgeRef e;
+                    e.start = parent; e.finish = sq;
+                    e.alpha = (double)wp * (1.0 / (double)(Wc - 1));
+                    const bool ok = config_valid(M, L, grid, e, my_lk);
+                    my_bad = ok ? 0 : 1;
+                }
+                if (my_bad) atomicOr(&X.edge_bad[p], 1);
+                if (my_lk) atomicAdd(&X.edge_lk[p], my_lk);
+            }
+        }
+    } else if (c == ncfg - 1) {
+        EdgeRef e;
+        e.start = parent; e.finish = parent; e.alpha = 0.0;
+        int lk = 0;
+        const bool ok = config_valid(M, L, grid, e, lk);
+        if (!ok) atomicOr(&X.state_bad, 1);
+        if (lk) atomicAdd(&X.state_lookups, lk);
+    }
+}
+
+// bookkeeping lane of primitive p, second half, in two steps: (i) limits, waypoint count, coordinates (-> X.coord[p]);
+// (ii) planning-link FK, goal test, heuristic.  (k_search starts the state-table probe of the coordinate between the two.)
+struct BookLane { bool limits_ok; int W, h, is_goal; };
+__device__ __forceinline__ void expand_book_coords(const ModelLds* __restrict__ M, ExpandLds& X, int p, BookLane& r)
+{
+    const int nv = MV_NVARS(M);
+    r.W = 0; r.h = 0; r.is_goal = 0;
+    const double* sq = X.sq[p];
+    r.limits_ok = check_joint_limits(M, sq);
+    if (r.limits_ok) {
+        r.W = expand_waypoint_count(M, X.parent, sq);
+        MV_UNROLL
+        for (int v = 0; v < nv; ++v) X.coord[p][v] = var_to_coord(M, v, sq[v]);
+    }
+}
+__device__ __forceinline__ void expand_book_goal(const ModelLds* __restrict__ M, const SmplxGridDev& grid, const SmplxBfsDev& bfs,
+                                                 const SmplxSpaceDev* __restrict__ Sq, const ExpandLds& X, int p, BookLane& r)
+{
+    if (!r.limits_ok) return;
+    const int nv = MV_NVARS(M);
+    double pw[3];
+    planning_fk(M, X.sq[p], pw);
+    if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
+        r.is_goal = 1;
+        MV_UNROLL
+        for (int v = 0; v < nv; ++v)
+            if (fabs((double)(X.coord[p][v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) r.is_goal = 0;
+    } else {                                      // XYZ goal :1672-1687
+        r.is_goal = fabs(pw[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(pw[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
+                    fabs(pw[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
+    }
+    int c[3];
+    world_to_cell(grid, pw, c);
+    r.h = bfs_cost_to_goal(bfs, c);
+}
+__device__ __forceinline__ BookLane expand_book_lane(const ModelLds* __restrict__ M, const SmplxGridDev& grid, const SmplxBfsDev& bfs,
+                                                     const SmplxSpaceDev* __restrict__ Sq, ExpandLds& X, int p)
+{
+    BookLane r;
+    expand_book_coords(M, X, p, r);
+    expand_book_goal(M, grid, bfs, Sq, X, p, r);
+    return r;
+}
+
+// the verdict of edge p once the waypoint lanes have reported: SMPLX_F_* flags; lookups = the reference's tally for the edge
+__device__ __forceinline__ int expand_verdict(const SmplxActionsDev& A, const ExpandLds& X, int p, bool have_action, const BookLane& b,
+                                              int& lookups)
+{
+    lookups = 0;
+    if (!have_action || !mprim_active(A, X.goal_dist, A.type[p])) return SMPLX_F_INACTIVE;
+    if (!b.limits_ok) return SMPLX_F_LIMITS;
+    lookups = X.edge_lk[p] + (b.W > 0 ? X.state_lookups : 0);
+    const bool ok = (b.W == 0) || (X.state_bad == 0 && X.edge_bad[p] == 0);
+    if (!ok) return SMPLX_F_COLLISION;
+    return SMPLX_F_VALID | (b.is_goal ? SMPLX_F_GOAL : 0);
+}
+
 // lanes of ONE wave exchange data through LDS: no block barrier needed, only that neither the compiler nor the memory
 // pipeline reorders the accesses (LDS operations of a wave execute in order)
 #define SMPLX_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-// ManipLattice::GetSuccs loop body (manip_lattice.cpp:254-305) for the state whose joint values are at parent_src (HBM or
-// pinned host memory), by all threads of the block (blockDim.x = smplx_small_block(nprims)).  The bookkeeping wave loads
-// the parent itself and starts at once; the other waves join at the first of three barriers (a caller may let them arrive
-// late: k_search sifts its heap meanwhile).  Ends with a barrier: on return X.parent, X.flags, X.sq, X.coord, X.h, X.lookups,
-// X.goal_dist, X.state_bad and X.state_lookups are final.
+// The whole loop body for the state whose joint values are at parent_src (HBM or pinned host memory), by all threads of the
+// block (blockDim.x = smplx_small_block(nprims)).  The bookkeeping wave loads the parent itself and starts at once; the
+// other waves join at the first of three barriers.  Ends with a barrier: on return X.parent, X.flags, X.sq, X.coord, X.h,
+// X.lookups, X.goal_dist, X.state_bad and X.state_lookups are final.
 __device__ __forceinline__ void expand_state_block(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxSpaceDev* __restrict__ S,
                                                    const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid, ExpandLds& X,
                                                    const double* __restrict__ parent_src)
@@ -1831,157 +1991,26 @@ __device__ __forceinline__ void expand_state_block(const ModelLds* __restrict__ 
     const int book0 = (ncfg + 63) / 64 * 64;                  // first lane of the bookkeeping wave
     if (t < nprims) { X.edge_bad[t] = 0; X.edge_lk[t] = 0; }
     if (t == 0) { X.state_bad = 0; X.state_lookups = 0; }
-    const double* parent = X.parent;
-
-    // ---- bookkeeping wave, first half: the parent's joint values, then the successor joint values of every primitive -> LDS ----
     const int bp = t - book0;                                 // primitive of a bookkeeping lane
     const bool book = bp >= 0 && bp < nprims;
     if (bp >= 0) {
         if (bp < nv) X.parent[bp] = parent_src[bp];
         SMPLX_WAVE_SYNC();
     }
-    int type = 0;
-    bool have_action = false;
-    if (book) {
-        type = A.type[bp];
-        if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) have_action = true;
-        else if (type == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT) have_action = true;
-        if (have_action) {
-            if (type == SMPLX_MP_LONG || type == SMPLX_MP_SHORT) {
-                // applyMotionPrimitive (manip_lattice_action_space.cpp:575-621)
-                double d0 = A.delta[bp][0], d1 = nv > 1 ? A.delta[bp][1] : 0.0;
-                if (A.xy_rotate_by_var3 && nv > 3) {
-                    double sn, cs;
-                    smplx_sincos(parent[3], &sn, &cs);
-                    const double a0 = d0, a1 = d1;
-                    d0 = cs * a0 + (-sn) * a1;
-                    d1 = sn * a0 + cs * a1;
-                }
-                MV_UNROLL
-                for (int v = 0; v < nv; ++v) {
-                    const double d = v == 0 ? d0 : (v == 1 ? d1 : A.delta[bp][v]);
-                    X.sq[bp][v] = d + parent[v];
-                }
-            } else {
-                MV_UNROLL
-                for (int v = 0; v < nv; ++v) X.sq[bp][v] = Sq->goal.angles[v];   // :551-559
-            }
-        }
-    }
-    if (bp == nprims) {
-        // ---- metric goal distance of the state (bfs_heuristic.cpp:129-138): the gate of its primitives ----
-        double pw[3];
-        planning_fk(M, parent, pw);
-        int c[3];
-        world_to_cell(grid, pw, c);
-        X.goal_dist = !bfs_in_bounds(bfs, c) ? (double)0x7FFFFFFF * grid.res : (double)bfs_dist(bfs, c) * grid.res;
-    }
+    const bool have_action = book && prim_has_action(A, Sq, bp);
+    if (have_action) expand_successor_values(M, A, Sq, X, bp);
+    if (bp == nprims) X.goal_dist = expand_goal_distance(M, grid, bfs, X);
     __syncthreads();   // every lane of every edge can read its successor's joint values and the gate from LDS
-
-    int h = 0, is_goal = 0, W = 0;
-    bool limits_ok = false;
-    if (t < book0 && t < ncfg - 1) {
-        // ---- config lanes: one waypoint each ----
-        const int p = t / SMPLX_SMALL_LANES, slot = t % SMPLX_SMALL_LANES;
-        const int ty = A.type[p];
-        const bool act = ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
-        if (act && mprim_active(A, X.goal_dist, ty)) {
-            const double* sq = X.sq[p];
-            if (check_joint_limits(M, sq)) {
-                double motion = 0.0;
-                MV_UNROLL
-                for (int v = 0; v < nv; ++v) {
-                    const int vt = MV_TYPE(M, v);
-                    const double sv = parent[v], fv = sq[v];
-                    if (vt == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
-                    else if (vt == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
-                    else if (vt == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
-                }
-                int Wc = 0;
-                if (motion != 0.0) {
-                    Wc = (int)ceil(motion / 0.05) + 1;
-                    if (Wc < 2) Wc = 2;
-                }
-                int my_bad = 0, my_lk = 0;
-                // waypoints slot+1, slot+8, ...: an edge longer than 7 waypoints wraps around its lanes
-                for (int wp = slot + 1; wp < Wc && !my_bad; wp += SMPLX_SMALL_LANES) {
-                    EdgeRef e;
-                    e.start = parent; e.finish = sq;
-                    e.alpha = (double)wp * (1.0 / (double)(Wc - 1));
-                    const bool ok = config_valid(M, L, grid, e, my_lk);
-                    my_bad = ok ? 0 : 1;
-                }
-                if (my_bad) atomicOr(&X.edge_bad[p], 1);
-                if (my_lk) atomicAdd(&X.edge_lk[p], my_lk);
-            }
-        }
-    } else if (t < book0 && t == ncfg - 1) {
-        // ---- the state itself: waypoint 0 of each edge (same code path as the other lanes of its wave) ----
-        EdgeRef e;
-        e.start = parent; e.finish = parent; e.alpha = 0.0;
-        int lk = 0;
-        const bool ok = config_valid(M, L, grid, e, lk);
-        if (!ok) atomicOr(&X.state_bad, 1);
-        if (lk) atomicAdd(&X.state_lookups, lk);
-    } else if (book && have_action) {
-        // ---- bookkeeping lane of primitive bp: limits, waypoint count, coordinates, planning-link FK, goal test, heuristic ----
-        const double* sq = X.sq[bp];
-        limits_ok = check_joint_limits(M, sq);
-        if (limits_ok) {
-            double motion = 0.0;
-            MV_UNROLL
-            for (int v = 0; v < nv; ++v) {
-                const int vt = MV_TYPE(M, v);
-                const double sv = parent[v], fv = sq[v];
-                if (vt == SMPLX_JT_CONTINUOUS) motion += MV_K(M, v) * fabs(smplx_shortest_angle_diff(fv, sv));
-                else if (vt == SMPLX_JT_REVOLUTE) motion += MV_K(M, v) * fabs(fv - sv);
-                else if (vt == SMPLX_JT_PRISMATIC) motion += fabs(fv - sv);
-            }
-            if (motion != 0.0) {
-                W = (int)ceil(motion / 0.05) + 1;
-                if (W < 2) W = 2;
-            }
-            int sc[SMPLX_MAX_VARS];
-            MV_UNROLL
-            for (int v = 0; v < nv; ++v) { sc[v] = var_to_coord(M, v, sq[v]); X.coord[bp][v] = sc[v]; }
-            double pw[3];
-            planning_fk(M, sq, pw);
-            if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
-                is_goal = 1;
-                MV_UNROLL
-                for (int v = 0; v < nv; ++v)
-                    if (fabs((double)(sc[v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) is_goal = 0;
-            } else {                                      // XYZ goal :1672-1687
-                is_goal = fabs(pw[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(pw[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
-                          fabs(pw[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
-            }
-            int c[3];
-            world_to_cell(grid, pw, c);
-            h = bfs_cost_to_goal(bfs, c);
-        }
-    }
+    BookLane b;
+    b.limits_ok = false; b.W = 0; b.h = 0; b.is_goal = 0;
+    if (t < book0) expand_config_lane(M, L, A, Sq, grid, X, t, ncfg);
+    else if (have_action) b = expand_book_lane(M, grid, bfs, Sq, X, bp);
     __syncthreads();   // the waypoint verdicts and the state's own check have landed in LDS
-
-    // ---- bookkeeping lanes: the verdict of their edge ----
     if (book) {
-        int flags;
-        int lookups = 0, hh = 0;
-        if (!have_action || !mprim_active(A, X.goal_dist, type)) {
-            flags = SMPLX_F_INACTIVE;
-        } else if (!limits_ok) {
-            flags = SMPLX_F_LIMITS;
-        } else {
-            lookups = X.edge_lk[bp] + (W > 0 ? X.state_lookups : 0);
-            const bool ok = (W == 0) || (X.state_bad == 0 && X.edge_bad[bp] == 0);
-            if (!ok) {
-                flags = SMPLX_F_COLLISION;
-            } else {
-                flags = SMPLX_F_VALID | (is_goal ? SMPLX_F_GOAL : 0);
-                hh = h;
-            }
-        }
+        int lookups;
+        const int flags = expand_verdict(A, X, bp, have_action, b, lookups);
         X.flags[bp] = flags;
-        X.h[bp] = hh;
+        X.h[bp] = (flags & SMPLX_F_VALID) ? b.h : 0;
         X.lookups[bp] = lookups;
     }
     __syncthreads();

@@ -8,52 +8,47 @@
 //                 here, by the workgroup, in its own commit order (manip_lattice.cpp:1302-1354) -- are the reference's.
 //
 // Who does what inside the workgroup (blockDim.x = smplx_small_block(nprims)):
-//   thread 0      the sequential part: the replan state machine, pop, the relaxation of the successors in primitive order
-//                 (the order decides ties in OPEN), INCONS
-//   all threads   the GetSuccs loop body of the popped state (expand_state_block: one configuration per lane), the state
-//                 table lookups / inserts of its successors (one lane per primitive), the prefetch of the successors'
-//                 search states, the recomputation of f and the level-parallel make() of an epsilon step
-// The first `LH` entries of the heap array live in LDS while the kernel runs (a sift is a chain of dependent reads: tens of
-// nanoseconds each in LDS, most of a microsecond in HBM); they are written back when the launch ends.
+//   the LAST wave   ("search wave") runs the search: the replan state machine, pop, the successors' joint values, limits,
+//                   coordinates, state-table probes, goal test and heuristic (lane p = primitive p), getOrCreateState, the
+//                   relaxation in primitive order (the order decides ties in OPEN), INCONS.  It works as ONE unit: what a
+//                   sequential program keeps in variables lives in its registers (uniform over the lanes), per-successor data
+//                   in the lane of the primitive, and a value another lane holds is read with v_readlane -- a single lane
+//                   walking LDS-resident structures costs a ~100-cycle round trip per step, which is what round 3 first
+//                   measured (13 us of relaxation per expansion).
+//                   The sifts of the heap are wave-parallel and exact: sift-up reads ALL ancestors of the slot at once
+//                   (lane j: index >> j), a ballot finds the level the sequential loop would stop at, the ancestors below it
+//                   move down in one scatter; sift-down fetches the five levels under the pivot at once (62 lanes) and
+//                   resolves the path in registers.
+//   the other waves check configurations: one waypoint of one edge per lane (expand_config_lane), between the two barriers
+//                   of a step.
+// The first `lh` entries of the heap array live in LDS while the kernel runs, the rest in HBM; the HBM-resident ancestors of
+// the slots a relaxation's pushes will take are fetched into LDS in one round trip before it (written through by every sift).
 //
 // A launch runs at most `max_steps` expansions and then stores its state in the query's SmplxSearchDev, so that the host
 // sees progress, can stop a search, and can enlarge buffers (SMPLX_SS_GROW) between launches.
 
-#define SMPLX_AC_LEVELS 12
+#define SMPLX_AC_LEVELS 16
 #define SMPLX_AC_SLOTS 128
+#define SMPLX_INFINITECOST 1000000000u     // SBPL INFINITECOST
 
+enum { SA_EVAL = 0, SA_SKIP = 1, SA_REORDER = 2, SA_EXIT = 3 };
+
+// what the waves of the block share
 struct SearchLds {
-    // working copy of the header fields that change
-    double curr_eps, satisfied_eps;
-    int heap_size, nstates, n_incons, n_log, n_succ;
-    int iteration, call_number, phase, num, expand_count, expand_count_init, err;
-    int dup_pushes, status, grow_what;
-    unsigned int goal_f;
-    long long committed_evals, gpu_evals, lookups;
-    long long ticks[8];
-    // the step in hand
-    int action, m, cnt, evals, from_cache;
-    unsigned int eg;
-    int succ_id[SMPLX_MAX_PRIMS], succ_cost[SMPLX_MAX_PRIMS], succ_prim[SMPLX_MAX_PRIMS];
-    int alias[SMPLX_MAX_PRIMS];
-    int lane_id[SMPLX_MAX_PRIMS];          // commit: state id of primitive p's successor (-1 = not in the table yet)
-    unsigned int lane_hash[SMPLX_MAX_PRIMS];
-    SmplxSState sst[SMPLX_MAX_PRIMS];      // the successors' search states, fetched together
-    int steps_left;
-    // ancestors of the slots the pushes of this relaxation will take, as far as they lie in HBM: level j (1 = parents)
-    // holds heap indices ac_lo[j] .. ac_hi[j] at ac_val[ac_base[j] ...]; written through by every sift of the relaxation
+    int action;                            // the step, published before its first barrier
+    double reorder_eps;
+    int reorder_size, reorder_dups;
+    // ancestors of the slots the pushes of a relaxation will take, as far as they lie in HBM: level j (1 = parents) holds
+    // heap indices ac_lo[j] .. ac_hi[j] at ac_val[ac_base[j] ...]
     int ac_nlev;
     int ac_lo[SMPLX_AC_LEVELS + 1], ac_hi[SMPLX_AC_LEVELS + 1], ac_base[SMPLX_AC_LEVELS + 1];
     unsigned long long ac_val[SMPLX_AC_SLOTS];
 };
 
-enum { SA_EXPAND = 0, SA_REORDER = 1, SA_EXIT = 2 };
-#define SMPLX_INFINITECOST 1000000000u     // SBPL INFINITECOST
-
-
 // a heap entry as one 64-bit word (the layout of SmplxHeapEntry: f in the low half, id in the high half): LDS and HBM
 // copies are single loads / stores
 typedef unsigned long long hent_t;
+#define HENT_ABSENT (~0ull)
 __device__ __forceinline__ unsigned int hent_f(hent_t e) { return (unsigned int)e; }
 __device__ __forceinline__ int hent_id(hent_t e) { return (int)(e >> 32); }
 __device__ __forceinline__ hent_t hent_make(unsigned int f, int id) { return (hent_t)f | ((hent_t)(unsigned int)id << 32); }
@@ -83,6 +78,9 @@ __device__ __forceinline__ void hset(const HeapRef& H, int i, hent_t e)
     H.st[hent_id(e)].heap_index = i;
 }
 
+// ---- the sequential forms (one thread): the reference's loops as they stand.  Used by the level-parallel make() and as the
+// specification of the wave-parallel forms below ----
+
 // intrusive_heap.hpp:346-377; size = number of elements (the reference's m_data.size() - 1)
 __device__ __forceinline__ void heap_percolate_down(const HeapRef& H, int pivot, int size)
 {
@@ -101,20 +99,6 @@ __device__ __forceinline__ void heap_percolate_down(const HeapRef& H, int pivot,
             pivot = s;
         } else break;
         left = pivot << 1; right = left + 1;
-    }
-    hset(H, pivot, tmp);
-}
-
-// intrusive_heap.hpp:379-395
-__device__ __forceinline__ void heap_percolate_up(const HeapRef& H, int pivot)
-{
-    const hent_t tmp = hget(H, pivot);
-    while (pivot != 1) {
-        const int p = pivot >> 1;
-        const hent_t ep = hget(H, p);
-        if (hent_f(ep) < hent_f(tmp)) break;
-        hset(H, pivot, ep);
-        pivot = p;
     }
     hset(H, pivot, tmp);
 }
@@ -142,10 +126,106 @@ __device__ __forceinline__ void heap_make_block(const HeapRef& H, int size, bool
     }
 }
 
+// ---- wave-level helpers: every lane of the wave is active and `lane_index` arguments are uniform ----
+__device__ __forceinline__ int wave_rl(int v, int lane_index) { return __builtin_amdgcn_readlane(v, lane_index); }
+__device__ __forceinline__ unsigned int wave_rlu(unsigned int v, int lane_index) { return (unsigned int)__builtin_amdgcn_readlane((int)v, lane_index); }
+__device__ __forceinline__ hent_t wave_rl64(hent_t v, int lane_index)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, lane_index);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), lane_index);
+    return (hent_t)lo | ((hent_t)hi << 32);
+}
+
+// a write to the HBM part of the heap also refreshes the ancestor cache where it holds that index
+__device__ __forceinline__ void ac_update(SearchLds& W, int i, hent_t e)
+{
+    const int nlev = W.ac_nlev;
+    for (int j = 1; j <= nlev; ++j)
+        if (i >= W.ac_lo[j] && i <= W.ac_hi[j]) { W.ac_val[W.ac_base[j] + i - W.ac_lo[j]] = e; return; }
+}
+__device__ __forceinline__ void hset_ac(const HeapRef& H, SearchLds& W, int i, hent_t e)
+{
+    if (i < H.lh) H.lds[i] = e;
+    else { H.hbm[i] = e; ac_update(W, i, e); }
+    H.st[hent_id(e)].heap_index = i;
+}
+
+// percolate_up by the whole wave (intrusive_heap.hpp:379-395): entry e sifts up from slot `start` (a push: the new last slot;
+// decrease: the entry's slot).  Lane j reads the ancestor start >> j; the sequential loop compares every ancestor IN ITS
+// ORIGINAL PLACE with e and stops at the first that is smaller, so a ballot finds that level; the ancestors below it move
+// down one level each, e takes the freed slot.  `cached` = the ancestor cache covers the walk (a push of the relaxation it
+// was built for): HBM-resident ancestors are read from LDS.
+__device__ __forceinline__ void heap_sift_up_wave(const HeapRef& H, SearchLds& W, int lane, int start, hent_t e, bool cached)
+{
+    const int j = lane;
+    const int idx = j < 31 ? (start >> j) : 0;
+    const bool anc = j >= 1 && idx >= 1;
+    hent_t ent = 0;
+    if (anc) {
+        if (idx < H.lh) ent = H.lds[idx];
+        else if (cached && j <= W.ac_nlev && idx >= W.ac_lo[j] && idx <= W.ac_hi[j]) ent = W.ac_val[W.ac_base[j] + idx - W.ac_lo[j]];
+        else ent = H.hbm[idx];
+    }
+    const unsigned long long m_anc = __ballot(anc), m_stop = __ballot(anc && hent_f(ent) < hent_f(e));
+    const int jstop = m_stop ? __ffsll((long long)m_stop) - 1 : __popcll(m_anc) + 1;   // ancestors are lanes 1 .. popc(m_anc)
+    if (anc && j < jstop) hset_ac(H, W, start >> (j - 1), ent);
+    if (j == 0) hset_ac(H, W, start >> (jstop - 1), e);
+}
+
+// percolate_down by the whole wave (intrusive_heap.hpp:346-377): entry tmp sifts down from `pivot`.  Lanes 0 .. 61 fetch the
+// five levels under the pivot at once; the path is resolved in registers (the loop reads every child in its original place:
+// moves only ever write to slots ABOVE what is read next); the chosen entries move up in one scatter.
+__device__ __forceinline__ void heap_sift_down_wave(const HeapRef& H, int lane, int pivot, int size, hent_t tmp)
+{
+    const int lv = 31 - __clz(lane + 2);                    // level below the pivot: 1 .. 5 for lanes 0 .. 61
+    const int off = lane + 2 - (1 << lv);
+    while (true) {
+        if ((pivot << 1) > size) break;
+        const int idx = (pivot << lv) + off;
+        hent_t ent = HENT_ABSENT;
+        if (lane < 62 && idx <= size) ent = hget(H, idx);
+        int c = 0, depth = 0;
+        unsigned long long chosen = 0;
+        bool stopped = false;
+#pragma unroll
+        for (int l = 1; l <= 5; ++l) {
+            if (stopped) continue;
+            const int li = (1 << l) - 2 + 2 * c;
+            const hent_t el = wave_rl64(ent, li), er = wave_rl64(ent, li + 1);
+            if (el == HENT_ABSENT) { stopped = true; continue; }
+            const bool right = er != HENT_ABSENT && !(hent_f(el) < hent_f(er));
+            const hent_t es = right ? er : el;
+            if (!(hent_f(es) < hent_f(tmp))) { stopped = true; continue; }
+            chosen |= 1ull << (li + (right ? 1 : 0));
+            c = 2 * c + (right ? 1 : 0);
+            depth = l;
+        }
+        if ((chosen >> lane) & 1ull) hset(H, idx >> 1, ent);
+        pivot = (pivot << depth) + c;
+        if (stopped) break;
+        // the next round reads below what this one moved: nothing it reads was written
+    }
+    if (lane == 0) hset(H, pivot, tmp);
+}
+
 // ARAStar::computeKey (arastar.cpp:579-582)
 __device__ __forceinline__ unsigned int search_key(double eps, unsigned int g, unsigned int h)
 {
     return g + (unsigned int)(long long)(eps * (double)h);
+}
+
+// Every OPEN entry of state `id` takes the state's new f (whole wave).  Only needed once a state has been pushed while
+// already in OPEN (the reference appends a state to INCONS once per improvement, arastar.cpp:563-565, and pushes every
+// INCONS entry, :180-184): its heap then holds the same element twice, and both see an f change because both point to it.
+__device__ __forceinline__ void heap_refresh_duplicates_wave(const HeapRef& H, SearchLds& W, int lane, int size, int id, unsigned int f)
+{
+    for (int i = 1 + lane; i <= size; i += 64) {
+        const hent_t e = hget(H, i);
+        if (hent_id(e) == id && hent_f(e) != f) {
+            const hent_t ne = hent_make(f, id);
+            if (i < H.lh) H.lds[i] = ne; else { H.hbm[i] = ne; ac_update(W, i, ne); }
+        }
+    }
 }
 
 __device__ __forceinline__ unsigned int coord_hash_lds(const LDS_AS int* c, int n)
@@ -172,7 +252,7 @@ __device__ __forceinline__ void sstate_reinit(SmplxSState& s, int call_number)
 
 typedef int __attribute__((ext_vector_type(4))) sk_int4;
 
-// write a state's fields back; heap_index only when the caller owns it (it is otherwise kept current by hset)
+// write a state's fields back; heap_index only when the caller owns it (it is otherwise kept current by the sifts)
 __device__ __forceinline__ void sstate_store(SmplxSState* dst, const SmplxSState& s, bool with_heap_index)
 {
     sk_int4 a;
@@ -183,174 +263,59 @@ __device__ __forceinline__ void sstate_store(SmplxSState* dst, const SmplxSState
     *reinterpret_cast<unsigned int*>(&dst->iteration_closed) = (unsigned int)s.iteration_closed | ((unsigned int)s.call_number << 16);
     dst->flags = s.flags;
 }
-
-__device__ __forceinline__ bool search_timed_out(const SmplxSearchDev& P, const SearchLds& W)
+__device__ __forceinline__ SmplxSState sstate_load(const SmplxSState* src)
 {
-    if (!P.bounded) return false;
-    if (W.satisfied_eps == __builtin_inf()) return W.num >= P.max_init;
-    return W.num >= P.max_rep;
+    const sk_int4 a = reinterpret_cast<const sk_int4*>(src)[0], b = reinterpret_cast<const sk_int4*>(src)[1];
+    SmplxSState s;
+    s.g = (unsigned int)a.x; s.h = (unsigned int)a.y; s.f = (unsigned int)a.z; s.eg = (unsigned int)a.w;
+    s.bp = b.x; s.heap_index = b.y;
+    s.iteration_closed = (unsigned short)((unsigned int)b.z & 0xFFFFu); s.call_number = (unsigned short)((unsigned int)b.z >> 16);
+    s.flags = (unsigned int)b.w;
+    return s;
 }
 
-// ---- sifts of the relaxation: reads of HBM-resident ancestors come from the cache built before it, writes go to both ----
-__device__ __forceinline__ void ac_update(SearchLds& W, int i, hent_t e)
-{
-    for (int j = 1; j <= W.ac_nlev; ++j)
-        if (i >= W.ac_lo[j] && i <= W.ac_hi[j]) { W.ac_val[W.ac_base[j] + i - W.ac_lo[j]] = e; return; }
-}
-__device__ __forceinline__ void hset_r(const HeapRef& H, SearchLds& W, int i, hent_t e)
-{
-    if (i < H.lh) H.lds[i] = e;
-    else { H.hbm[i] = e; ac_update(W, i, e); }
-    H.st[hent_id(e)].heap_index = i;
-}
-// Every OPEN entry of state `id` takes the state's new f.  Only needed once a state has been pushed while already in OPEN
-// (the reference appends a state to INCONS once per improvement, arastar.cpp:563-565, and pushes every INCONS entry,
-// :180-184): its heap then holds the same element twice, and both see an f change because both point to it.
-__device__ __forceinline__ void heap_refresh_duplicates_r(const HeapRef& H, SearchLds& W, int size, int id, unsigned int f)
-{
-    for (int i = 1; i <= size; ++i) {
-        const hent_t e = hget(H, i);
-        if (hent_id(e) == id && hent_f(e) != f) {
-            const hent_t ne = hent_make(f, id);
-            if (i < H.lh) H.lds[i] = ne; else { H.hbm[i] = ne; ac_update(W, i, ne); }
-        }
-    }
-}
-// percolate_up from an arbitrary position (decrease-key)
-__device__ __forceinline__ void heap_percolate_up_r(const HeapRef& H, SearchLds& W, int pivot)
-{
-    const hent_t tmp = hget(H, pivot);
-    while (pivot != 1) {
-        const int p = pivot >> 1;
-        const hent_t ep = hget(H, p);
-        if (hent_f(ep) < hent_f(tmp)) break;
-        hset_r(H, W, pivot, ep);
-        pivot = p;
-    }
-    hset_r(H, W, pivot, tmp);
-}
-// push (intrusive_heap.hpp:145-153) into slot `pivot` = size + 1: the walk towards the root reads LDS only
-__device__ __forceinline__ void heap_push_r(const HeapRef& H, SearchLds& W, int pivot, hent_t e)
-{
-    int j = 0;    // level above the slot
-    while (pivot != 1) {
-        const int p = pivot >> 1;
-        hent_t ep;
-        if (p < H.lh) ep = H.lds[p];
-        else if (j + 1 <= W.ac_nlev && p >= W.ac_lo[j + 1] && p <= W.ac_hi[j + 1]) ep = W.ac_val[W.ac_base[j + 1] + p - W.ac_lo[j + 1]];
-        else ep = H.hbm[p];
-        if (hent_f(ep) < hent_f(e)) break;
-        // the ancestor moves down one level
-        if (pivot < H.lh) H.lds[pivot] = ep;
-        else {
-            H.hbm[pivot] = ep;
-            if (j >= 1 && j <= W.ac_nlev && pivot >= W.ac_lo[j] && pivot <= W.ac_hi[j]) W.ac_val[W.ac_base[j] + pivot - W.ac_lo[j]] = ep;
-        }
-        H.st[hent_id(ep)].heap_index = pivot;
-        pivot = p;
-        ++j;
-    }
-    if (pivot < H.lh) H.lds[pivot] = e;
-    else {
-        H.hbm[pivot] = e;
-        if (j >= 1 && j <= W.ac_nlev && pivot >= W.ac_lo[j] && pivot <= W.ac_hi[j]) W.ac_val[W.ac_base[j] + pivot - W.ac_lo[j]] = e;
-    }
-    H.st[hent_id(e)].heap_index = pivot;
-}
-
-// percolate_down for the pop (intrusive_heap.hpp:346-377).  Below the LDS part of the array every level would be a
-// dependent HBM round trip: the three levels under the pivot (2 + 4 + 8 entries) are requested together instead and the
-// walk continues in registers.
-__device__ __forceinline__ hent_t hbm_or_absent(const HeapRef& H, int i, int size) { return i <= size ? H.hbm[i] : ~0ull; }
-__device__ __forceinline__ void heap_percolate_down_pf(const HeapRef& H, int pivot, int size)
-{
-    if (pivot > size) return;
-    const hent_t tmp = hget(H, pivot);
-    bool done = false;
-    while (!done) {
-        const int left = pivot << 1;
-        if (left > size) break;
-        if (left + 1 < H.lh) {
-            hent_t es = H.lds[left];
-            int s = left;
-            if (left + 1 <= size) {
-                const hent_t er = H.lds[left + 1];
-                if (!(hent_f(es) < hent_f(er))) { es = er; s = left + 1; }
-            }
-            if (hent_f(es) < hent_f(tmp)) { hset(H, pivot, es); pivot = s; }
-            else done = true;
-            continue;
-        }
-        // three levels below `pivot`, all loads in flight at once (an index beyond the heap reads as absent)
-        const int b1 = left, b2 = left << 1, b3 = left << 2;
-        hent_t c1[2], c2[4], c3[8];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) c1[k] = b1 + k <= size ? hget(H, b1 + k) : ~0ull;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c2[k] = hbm_or_absent(H, b2 + k, size);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c3[k] = hbm_or_absent(H, b3 + k, size);
-        // level 1
-        int s1 = 0;
-        hent_t e1 = c1[0];
-        if (b1 + 1 <= size && !(hent_f(c1[0]) < hent_f(c1[1]))) { s1 = 1; e1 = c1[1]; }
-        if (!(hent_f(e1) < hent_f(tmp))) { done = true; continue; }
-        hset(H, pivot, e1);
-        pivot = b1 + s1;
-        // level 2: children of b1 + s1 are b2 + 2 s1 + {0, 1}
-        const hent_t l2 = s1 ? c2[2] : c2[0], r2 = s1 ? c2[3] : c2[1];
-        const int i2 = b2 + 2 * s1;
-        if (i2 > size) { done = true; continue; }
-        int s2 = 0;
-        hent_t e2 = l2;
-        if (i2 + 1 <= size && !(hent_f(l2) < hent_f(r2))) { s2 = 1; e2 = r2; }
-        if (!(hent_f(e2) < hent_f(tmp))) { done = true; continue; }
-        hset(H, pivot, e2);
-        pivot = i2 + s2;
-        // level 3: children of i2 + s2 are b3 + 4 s1 + 2 s2 + {0, 1}
-        const int q = 2 * s1 + s2;
-        const hent_t l3 = q == 0 ? c3[0] : (q == 1 ? c3[2] : (q == 2 ? c3[4] : c3[6]));
-        const hent_t r3 = q == 0 ? c3[1] : (q == 1 ? c3[3] : (q == 2 ? c3[5] : c3[7]));
-        const int i3 = b3 + 2 * q;
-        if (i3 > size) { done = true; continue; }
-        int s3 = 0;
-        hent_t e3 = l3;
-        if (i3 + 1 <= size && !(hent_f(l3) < hent_f(r3))) { s3 = 1; e3 = r3; }
-        if (!(hent_f(e3) < hent_f(tmp))) { done = true; continue; }
-        hset(H, pivot, e3);
-        pivot = i3 + s3;
-    }
-    hset(H, pivot, tmp);
-}
-
-// one probe sequence of the state table with plain 16-byte loads: the id of the coordinate, or -1 and the empty slot the
-// probing ended at.  Only the workgroup that owns the query writes its table while the kernel runs (plain stores, earlier
-// in program order or before a barrier), so what it reads is current.
+// One probe sequence of the state table with plain 16-byte loads.  Only the workgroup that owns the query writes its table
+// while the kernel runs, so what it reads is current.  table_probe_start issues the loads of the home slot (they land
+// behind the planning-link FK); table_probe_finish looks at them and walks on if it has to.
 struct TableProbe { int id; unsigned int free_slot; };
-__device__ __forceinline__ TableProbe table_probe_own(const SmplxTableDev& T, const LDS_AS int* c, int nv, unsigned int hash)
+struct TableProbeLoads { sk_int4 w[4]; unsigned int slot; };
+__device__ __forceinline__ void table_slot_load(const SmplxTableDev& T, unsigned int slot, int nv, sk_int4 w[4])
+{
+    const sk_int4* sl = reinterpret_cast<const sk_int4*>(T.slots + (size_t)slot * T.stride);
+    const int nw = (nv + 1 + 3) / 4;       // 16-byte words that hold the tag and the coordinate (stride is a multiple of 8 ints)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nw) w[k] = sl[k];
+}
+__device__ __forceinline__ bool table_slot_match(const sk_int4 w[4], const LDS_AS int* c, int nv)
+{
+    const int nw = (nv + 1 + 3) / 4;
+    bool same = w[0].x > 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= nw) continue;
+        const int base = 4 * k - 1;        // coordinate index of .x
+        if (k > 0 && base < nv) same = same && w[k].x == c[base];
+        if (base + 1 < nv) same = same && w[k].y == c[base + 1];
+        if (base + 2 < nv) same = same && w[k].z == c[base + 2];
+        if (base + 3 < nv) same = same && w[k].w == c[base + 3];
+    }
+    return same;
+}
+__device__ __forceinline__ TableProbeLoads table_probe_start(const SmplxTableDev& T, int nv, unsigned int hash)
+{
+    TableProbeLoads r;
+    r.slot = hash & T.mask;
+    table_slot_load(T, r.slot, nv, r.w);
+    return r;
+}
+__device__ __forceinline__ TableProbe table_probe_finish(const SmplxTableDev& T, TableProbeLoads& ld, const LDS_AS int* c, int nv)
 {
     TableProbe r;
-    unsigned int i = hash & T.mask;
     while (true) {
-        const sk_int4* sl = reinterpret_cast<const sk_int4*>(T.slots + (size_t)i * T.stride);
-        sk_int4 w[4];
-        const int nw = (nv + 1 + 3) / 4;       // 16-byte words that hold the tag and the coordinate (stride is a multiple of 8 ints)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < nw) w[k] = sl[k];
-        const int tag = w[0].x;
-        if (tag == 0) { r.id = -1; r.free_slot = i; return r; }
-        bool same = tag > 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= nw) continue;
-            const int base = 4 * k - 1;        // coordinate index of .x
-            if (k > 0 && base < nv) same = same && w[k].x == c[base];
-            if (base + 1 < nv) same = same && w[k].y == c[base + 1];
-            if (base + 2 < nv) same = same && w[k].z == c[base + 2];
-            if (base + 3 < nv) same = same && w[k].w == c[base + 3];
-        }
-        if (same) { r.id = tag - 1; r.free_slot = 0; return r; }
-        i = (i + 1) & T.mask;
+        if (ld.w[0].x == 0) { r.id = -1; r.free_slot = ld.slot; return r; }
+        if (table_slot_match(ld.w, c, nv)) { r.id = ld.w[0].x - 1; r.free_slot = 0; return r; }
+        ld.slot = (ld.slot + 1) & T.mask;
+        table_slot_load(T, ld.slot, nv, ld.w);
     }
 }
 __device__ __forceinline__ void table_store_own(const SmplxTableDev& T, unsigned int slot, const LDS_AS int* c, int nv, int id)
@@ -359,6 +324,16 @@ __device__ __forceinline__ void table_store_own(const SmplxTableDev& T, unsigned
     for (int v = 0; v < nv; ++v) sl[1 + v] = c[v];
     sl[0] = id + 1;
 }
+
+// the search's variables: registers of the search wave, the same value in every lane
+struct SearchRegs {
+    double curr_eps, satisfied_eps;
+    int heap_size, nstates, n_incons, n_log, n_succ;
+    int iteration, call_number, phase, num, expand_count, expand_count_init, err;
+    int dup_pushes, status, grow_what, steps_left;
+    unsigned int goal_f;
+    long long committed_evals, gpu_evals, lookups;
+};
 
 extern "C" __global__ void __launch_bounds__(512)
 k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, int* __restrict__ status_out)
@@ -380,15 +355,19 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
         }
     }
     for (int i = t; i < (int)(sizeof(SmplxSearchDev) / 4); i += blockDim.x) ((int*)&Ph)[i] = ((const int*)Pd)[i];
+    if (t == 0) { W.action = SA_SKIP; W.ac_nlev = 0; }
     __syncthreads();
-    const SmplxSearchDev* const P = &Ph;         // read-only view; what changes goes through W and back to Pd at the end
+    const SmplxSearchDev* const P = &Ph;         // read-only view; what changes lives in the search wave and goes back to Pd at the end
     ModelLds Mv;
     ThreadLds L = setup_lds(S, smem, &Mv, blockDim.x);
     const ModelLds* M = &Mv;
     const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
+    const SmplxBfsDev bfs = Sq->bfs;
     const SmplxTableDev table = Sq->table;
     const int nprims = A.nprims, nv = MV_NVARS(M);
+    const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
+    const int book0 = (ncfg + 63) / 64 * 64;                  // first thread of the search wave
     HeapRef H;
     {
         // the heap cache sits behind the model and the per-thread scratch of the expansion (setup_lds)
@@ -406,412 +385,480 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
         H.st = P->st;
         H.lh = lh;
     }
-    // ---- load the working state ----
-    if (t == 0) {
-        W.curr_eps = P->curr_eps; W.satisfied_eps = P->satisfied_eps;
-        W.heap_size = P->heap_size; W.nstates = P->nstates; W.n_incons = P->n_incons; W.n_log = P->n_log; W.n_succ = P->n_succ;
-        W.iteration = P->iteration; W.call_number = P->call_number; W.phase = P->phase; W.num = P->num;
-        W.expand_count = P->expand_count; W.expand_count_init = P->expand_count_init; W.err = P->err;
-        W.dup_pushes = P->dup_pushes; W.goal_f = P->goal_f;
-        W.committed_evals = P->committed_evals; W.gpu_evals = P->gpu_evals; W.lookups = P->lookups;
-        for (int k = 0; k < 8; ++k) W.ticks[k] = P->ticks[k];
-        W.action = SA_EXPAND; W.status = SMPLX_SS_RUNNING; W.grow_what = 0;
-        W.steps_left = max_steps;
-        W.ac_nlev = 0;
-    }
-    __syncthreads();
     {
-        const int n = W.heap_size + 1 < lh ? W.heap_size + 1 : lh;
+        const int n = P->heap_size + 1 < lh ? P->heap_size + 1 : lh;
         for (int i = t; i < n; i += blockDim.x) H.lds[i] = H.hbm[i];
     }
     __syncthreads();
-    if (t == 0 && W.phase == 0) {
-        // ---- ARAStar::replan, from scratch (arastar.cpp:107-167): empty OPEN and INCONS, new call number, the start state
-        // with g = 0 into OPEN ----
-        W.heap_size = 0; W.n_incons = 0; W.n_log = 0;
-        W.call_number = (W.call_number + 1) & 0xFFFF;
-        if (W.call_number == 0) W.call_number = 1;
-        SmplxSState ss = P->st[P->start_id], gs = P->st[0];
-        sstate_reinit(ss, W.call_number);
-        sstate_reinit(gs, W.call_number);
-        W.iteration = 1;
-        W.curr_eps = P->initial_eps;
-        W.satisfied_eps = __builtin_inf();
-        ss.g = 0;
-        ss.f = search_key(W.curr_eps, ss.g, ss.h);
-        sstate_store(&P->st[P->start_id], ss, true);
-        if (P->start_id != 0) sstate_store(&P->st[0], gs, true);
-        W.goal_f = P->start_id == 0 ? ss.f : gs.f;
-        W.heap_size = 1;
-        hset(H, 1, hent_make(ss.f, P->start_id));
-        W.num = 0; W.err = 0; W.expand_count = 0; W.expand_count_init = 0; W.dup_pushes = 0;
-        W.phase = 1;
-    }
 
-    long long tick = 0;
-    if (t == 0) tick = (long long)wall_clock64();
-#define SK_TICK(k) do { const long long now_ = (long long)wall_clock64(); W.ticks[k] += now_ - tick; tick = now_; } while (0)
+    if (t < book0) {
+        // =============================== the config waves ===============================
+        while (true) {
+            __syncthreads();                                       // A: the step is published
+            const int action = W.action;
+            if (action == SA_EXIT) break;
+            if (action == SA_EVAL) expand_config_lane(M, L, A, Sq, grid, X, t, ncfg);
+            if (action == SA_REORDER) {
+                const int size = W.reorder_size;
+                const double eps = W.reorder_eps;
+                for (int i = 1 + t; i <= size; i += blockDim.x) {     // f of every OPEN entry under the new epsilon (arastar.cpp:571-577)
+                    const int eid = hent_id(hget(H, i));
+                    SmplxSState* ss = &P->st[eid];
+                    const unsigned int f = search_key(eps, ss->g, ss->h);
+                    ss->f = f;
+                    hput(H, i, hent_make(f, eid));
+                }
+                __syncthreads();
+                heap_make_block(H, size, W.reorder_dups > 0);
+            }
+            __syncthreads();                                       // B: the waypoint verdicts have landed
+        }
+    } else {
+        // =============================== the search wave ===============================
+        const int lane = t - book0;
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        SearchRegs R;
+        R.curr_eps = P->curr_eps; R.satisfied_eps = P->satisfied_eps;
+        R.heap_size = P->heap_size; R.nstates = P->nstates; R.n_incons = P->n_incons; R.n_log = P->n_log; R.n_succ = P->n_succ;
+        R.iteration = P->iteration; R.call_number = P->call_number; R.phase = P->phase; R.num = P->num;
+        R.expand_count = P->expand_count; R.expand_count_init = P->expand_count_init; R.err = P->err;
+        R.dup_pushes = P->dup_pushes; R.goal_f = P->goal_f;
+        R.committed_evals = P->committed_evals; R.gpu_evals = P->gpu_evals; R.lookups = P->lookups;
+        R.status = SMPLX_SS_RUNNING; R.grow_what = 0; R.steps_left = max_steps;
+        long long ticks[8];
+        for (int k = 0; k < 8; ++k) ticks[k] = P->ticks[k];
+        long long tick = (long long)wall_clock64();
+#define SK_TICK(k) do { const long long now_ = (long long)wall_clock64(); ticks[k] += now_ - tick; tick = now_; } while (0)
 
-    // =========================== thread 0: what happens next (Search::resume / improve_path) ===========================
-    // Decides the step -- expand state m, start a new epsilon, or leave -- WITHOUT popping yet: the pop's sift runs after the
-    // barrier that publishes m, beside the first phase of the expansion.
-    auto select = [&]() {
-        int action = -1;
-        while (action < 0) {
-            if (W.phase == 1) {
-                // arastar.cpp:169-186
-                if (!(W.satisfied_eps > P->final_eps)) { W.phase = 3; action = SA_EXIT; break; }
-                if (W.curr_eps == W.satisfied_eps) {
-                    if (!P->improve) { W.phase = 3; action = SA_EXIT; break; }
-                    if (W.heap_size + W.n_incons > P->cap_heap) { W.status = SMPLX_SS_GROW; W.grow_what = 1; action = SA_EXIT; break; }
-                    action = SA_REORDER;
+        if (R.phase == 0) {
+            // ---- ARAStar::replan, from scratch (arastar.cpp:107-167): empty OPEN and INCONS, new call number, the start
+            // state with g = 0 into OPEN ----
+            R.heap_size = 0; R.n_incons = 0; R.n_log = 0;
+            R.call_number = (R.call_number + 1) & 0xFFFF;
+            if (R.call_number == 0) R.call_number = 1;
+            SmplxSState ss = sstate_load(&P->st[P->start_id]), gs = sstate_load(&P->st[0]);
+            sstate_reinit(ss, R.call_number);
+            sstate_reinit(gs, R.call_number);
+            R.iteration = 1;
+            R.curr_eps = P->initial_eps;
+            R.satisfied_eps = __builtin_inf();
+            ss.g = 0;
+            ss.f = search_key(R.curr_eps, ss.g, ss.h);
+            R.goal_f = P->start_id == 0 ? ss.f : gs.f;
+            R.heap_size = 1;
+            if (lane == 0) {
+                sstate_store(&P->st[P->start_id], ss, true);
+                if (P->start_id != 0) sstate_store(&P->st[0], gs, true);
+                hset(H, 1, hent_make(ss.f, P->start_id));
+            }
+            R.num = 0; R.err = 0; R.expand_count = 0; R.expand_count_init = 0; R.dup_pushes = 0;
+            R.phase = 1;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        // the goal distance of a state follows from its heuristic when h = cost_per_cell * BFS distance is invertible
+        // (bfs_heuristic.cpp:129-138 / 355-366: both read the BFS cell of the same planning-link position)
+        const int cpc = bfs.cost_per_cell;
+        const bool gd_from_h = cpc > 0 && (32767 % cpc) != 0;
+
+        while (true) {
+            // =========================== what happens next (ARAStar::replan / improvePath) ===========================
+            int action = -1, m = 0;
+            while (action < 0) {
+                if (R.phase == 1) {
+                    // arastar.cpp:169-186
+                    if (!(R.satisfied_eps > P->final_eps)) { R.phase = 3; action = SA_EXIT; break; }
+                    if (R.curr_eps == R.satisfied_eps) {
+                        if (!P->improve) { R.phase = 3; action = SA_EXIT; break; }
+                        if (R.heap_size + R.n_incons > P->cap_heap) { R.status = SMPLX_SS_GROW; R.grow_what = 1; action = SA_EXIT; break; }
+                        action = SA_REORDER;
+                        break;
+                    }
+                    R.phase = 2;
+                }
+                // ---- one step of improvePath (arastar.cpp:486-527) ----
+                int err = -1;
+                hent_t top = 0;
+                if (R.heap_size == 0) err = 5;                                          // EXHAUSTED_OPEN_LIST
+                else {
+                    top = hget(H, 1);
+                    bool timed_out = false;
+                    if (P->bounded) timed_out = R.satisfied_eps == __builtin_inf() ? R.num >= P->max_init : R.num >= P->max_rep;
+                    if (hent_f(top) >= R.goal_f || hent_id(top) == 0) err = 0;          // SUCCESS
+                    else if (timed_out) err = 4;                                        // TIMED_OUT
+                }
+                if (err >= 0) {
+                    // back in replan (arastar.cpp:188-197)
+                    if (R.curr_eps == P->initial_eps) R.expand_count_init += R.num;
+                    R.phase = 1;
+                    R.err = err;
+                    if (err != 0) { R.phase = 3; action = SA_EXIT; break; }
+                    R.satisfied_eps = R.curr_eps;
+                    continue;
+                }
+                if (R.steps_left <= 0) { action = SA_EXIT; break; }                      // this launch has done its share
+                // room for one more expansion?  (checked before anything is popped: the host enlarges and launches again)
+                if (R.nstates + nprims > P->cap_states || R.heap_size + nprims > P->cap_heap || R.n_incons + nprims > P->cap_incons ||
+                    R.n_log + 1 > P->cap_log || R.n_succ + nprims > P->cap_succ || (unsigned int)(2 * (R.nstates + nprims)) > table.mask + 1u) {
+                    R.status = SMPLX_SS_GROW; R.grow_what = 2;
+                    action = SA_EXIT;
                     break;
                 }
-                W.phase = 2;
+                --R.steps_left;
+                m = hent_id(top);
+                action = SA_EVAL;
             }
-            // ---- one step of improvePath (arastar.cpp:486-527) ----
-            int err = -1;
-            hent_t top = 0;
-            if (W.heap_size == 0) err = 5;                                          // EXHAUSTED_OPEN_LIST
-            else {
-                top = hget(H, 1);
-                if (hent_f(top) >= W.goal_f || hent_id(top) == 0) err = 0;          // SUCCESS
-                else if (search_timed_out(*P, W)) err = 4;                          // TIMED_OUT
-            }
-            if (err >= 0) {
-                // back in replan (arastar.cpp:188-197)
-                if (W.curr_eps == P->initial_eps) W.expand_count_init += W.num;
-                W.phase = 1;
-                W.err = err;
-                if (err != 0) { W.phase = 3; action = SA_EXIT; break; }
-                W.satisfied_eps = W.curr_eps;
-                continue;
-            }
-            if (W.steps_left <= 0) { action = SA_EXIT; break; }                      // this launch has done its share
-            // room for one more expansion?  (checked before anything is popped: the host enlarges and launches again)
-            if (W.nstates + nprims > P->cap_states || W.heap_size + nprims > P->cap_heap || W.n_incons + nprims > P->cap_incons ||
-                W.n_log + 1 > P->cap_log || W.n_succ + nprims > P->cap_succ || (unsigned int)(2 * (W.nstates + nprims)) > table.mask + 1u) {
-                W.status = SMPLX_SS_GROW; W.grow_what = 2;
-                action = SA_EXIT;
+
+            if (action == SA_EXIT) {
+                if (lane == 0) W.action = SA_EXIT;
+                __syncthreads();                                   // A
                 break;
             }
-            --W.steps_left;
-            W.m = hent_id(top);
-            action = SA_EXPAND;
-        }
-        W.action = action;
-    };
-    if (t == 0) { select(); SK_TICK(1); }
 
-    while (true) {
-        __syncthreads();       // the step is decided; everything the previous step wrote is visible
-        const int action = W.action;
-        if (action == SA_EXIT) break;
-
-        if (action == SA_REORDER) {
-            // =========================== a new epsilon (arastar.cpp:174-186, 571-577) ===========================
-            if (t == 0) {
-                ++W.iteration;
-                W.curr_eps -= P->delta_eps;
-                W.curr_eps = W.curr_eps > P->final_eps ? W.curr_eps : P->final_eps;
-                for (int i = 0; i < W.n_incons; ++i) {
+            if (action == SA_REORDER) {
+                // =========================== a new epsilon (arastar.cpp:174-186, 571-577) ===========================
+                ++R.iteration;
+                R.curr_eps -= P->delta_eps;
+                R.curr_eps = R.curr_eps > P->final_eps ? R.curr_eps : P->final_eps;
+                for (int i = 0; i < R.n_incons; ++i) {
                     const int sid = P->incons[i];
-                    SmplxSState* ss = &P->st[sid];
-                    if (ss->heap_index != 0) { ss->flags |= 1u; ++W.dup_pushes; }   // already in OPEN: the same element twice
-                    ++W.heap_size;
-                    hset(H, W.heap_size, hent_make(ss->f, sid));
-                    heap_percolate_up(H, W.heap_size);
+                    const SmplxSState ss = sstate_load(&P->st[sid]);
+                    if (ss.heap_index != 0) {                       // already in OPEN: the same element twice from now on
+                        if (lane == 0) P->st[sid].flags = ss.flags | 1u;
+                        ++R.dup_pushes;
+                    }
+                    ++R.heap_size;
+                    heap_sift_up_wave(H, W, lane, R.heap_size, hent_make(ss.f, sid), false);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the next push reads what this one stored
                 }
-                W.n_incons = 0;
-            }
-            __syncthreads();
-            // f of every OPEN entry under the new epsilon
-            const int size = W.heap_size;
-            const double eps = W.curr_eps;
-            for (int i = 1 + t; i <= size; i += blockDim.x) {
-                const int eid = hent_id(hget(H, i));
-                SmplxSState* ss = &P->st[eid];
-                const unsigned int f = search_key(eps, ss->g, ss->h);
-                ss->f = f;
-                hput(H, i, hent_make(f, eid));
-            }
-            __syncthreads();
-            heap_make_block(H, size, W.dup_pushes > 0);
-            if (t == 0) {
-                const SmplxSState* gs = &P->st[0];
-                W.goal_f = gs->f;     // (the goal state is re-initialised when a call starts: its f is this call's)
-                W.phase = 2;
+                R.n_incons = 0;
+                if (lane == 0) { W.action = SA_REORDER; W.reorder_size = R.heap_size; W.reorder_eps = R.curr_eps; W.reorder_dups = R.dup_pushes; }
+                __syncthreads();                                   // A
+                {
+                    const int size = R.heap_size;
+                    for (int i = 1 + t; i <= size; i += blockDim.x) {
+                        const int eid = hent_id(hget(H, i));
+                        SmplxSState* ss = &P->st[eid];
+                        const unsigned int f = search_key(R.curr_eps, ss->g, ss->h);
+                        ss->f = f;
+                        hput(H, i, hent_make(f, eid));
+                    }
+                    __syncthreads();
+                    heap_make_block(H, size, R.dup_pushes > 0);
+                }
+                __syncthreads();                                   // B
+                R.goal_f = P->st[0].f;      // (the goal state is re-initialised when a call starts: its f is this call's)
+                R.phase = 2;
                 SK_TICK(5);
-                select();
-                SK_TICK(1);
+                continue;
             }
-            continue;
-        }
 
-        // =========================== expand state m (arastar.cpp:513-519, 531-568) ===========================
-        const int m = W.m;
-        const int off = P->done_off[m];              // >= 0: expanded before (a later ARA* iteration): the committed list serves
-        if (t == 0) {
-            // ---- pop (intrusive_heap.hpp:155-166); meanwhile the last wave forms the successors' joint values ----
-            SmplxSState* sm = &P->st[m];
-            const unsigned int g = sm->g;            // in flight together with the heap's last entry
-            const hent_t last = hget(H, W.heap_size);
-            sm->heap_index = 0;
-            --W.heap_size;
-            if (W.heap_size >= 1) {
-                hput(H, 1, last);
-                heap_percolate_down_pf(H, 1, W.heap_size);
-            }
-            sm->iteration_closed = (unsigned short)W.iteration;
-            sm->eg = g;
-            P->log[W.n_log++] = m;
-            W.eg = g;
-            SK_TICK(1);
-        }
-        if (off < 0) {
-            // ---- GetSuccs loop body (manip_lattice.cpp:254-305) on the lanes ----
-            expand_state_block(M, L, S, Sq, grid, X, P->q + (size_t)m * nv);
-            if (t == 0) SK_TICK(2);
-        }
-        if (t >= 64) continue;     // the rest of the step is the first wave's; the others wait at the barrier on top
-        // what thread 0 stored while popping (the state's closing, moved heap entries) is read below by OTHER lanes of this wave:
-        // wait until those stores have landed (nothing is outstanding when the expansion's barriers lie in between)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-
-        // ---- wave 0, lane p = primitive p: getOrCreateState for every valid successor (manip_lattice.cpp:1302-1354), then
-        // the successors' search states and the HBM-resident ancestors of the slots their pushes will take ----
-        const int lane = t;
-        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        int cnt, sid = -1, k = -1;                   // this lane's successor: state id, position in the list
-        bool valid, fresh = false;                   // fresh: the state was created by this expansion
-        unsigned int fresh_h = 0;
-        if (off >= 0) {
-            const int dc = P->done_cnt[m];
-            cnt = dc & 0xFF;
-            valid = lane < cnt;
-            k = lane;
-            if (valid) {
-                const SmplxSucc sc = P->succ[off + lane];
-                sid = sc.id;
-                W.succ_id[lane] = sid;
-                W.succ_cost[lane] = sc.cost_prim & 0xFFFFFF;
-            }
-            if (lane == 0) { W.cnt = cnt; W.evals = dc >> 8; }
-        } else {
-            const bool in = lane < nprims;
-            const int flags = in ? X.flags[lane] : SMPLX_F_INACTIVE;
-            valid = (flags & SMPLX_F_VALID) != 0;
-            int id = -1;
-            unsigned int hash = 0, free_slot = 0;
-            if (valid) {
-                hash = coord_hash_lds((const LDS_AS int*)X.coord[lane], nv);
-                const TableProbe pr = table_probe_own(table, (const LDS_AS int*)X.coord[lane], nv, hash);
-                id = pr.id;
-                free_slot = pr.free_slot;
-            }
-            // two successors of this expansion with the same new coordinate: the lower primitive creates the state
-            const bool unknown = valid && id < 0;
-            const unsigned long long m_unknown = __ballot(unknown);
-            int dup_of = -1;
-            for (int j = 0; j < nprims; ++j) {
-                const unsigned int hj = (unsigned int)__shfl((int)hash, j);
-                if (j < lane && unknown && dup_of < 0 && ((m_unknown >> j) & 1ull) && hj == hash) {
-                    bool same = true;
-                    for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
-                    if (same) dup_of = j;
-                }
-            }
-            const bool is_new = unknown && dup_of < 0;
-            const unsigned long long m_new = __ballot(is_new), m_valid = __ballot(valid), m_eval = __ballot(in && !(flags & SMPLX_F_INACTIVE));
-            // two new coordinates whose probing ended at the same empty slot (rare): the later one probes again below
-            bool clash = false;
-            for (int j = 0; j < nprims; ++j) {
-                const unsigned int fj = (unsigned int)__shfl((int)free_slot, j);
-                if (j < lane && is_new && ((m_new >> j) & 1ull) && fj == free_slot) clash = true;
-            }
-            if (is_new) {
-                id = W.nstates + __popcll(m_new & below);
-                if (!clash) table_store_own(table, free_slot, (const LDS_AS int*)X.coord[lane], nv, id);
-                for (int v = 0; v < nv; ++v) { P->coord[(size_t)id * nv + v] = X.coord[lane][v]; P->q[(size_t)id * nv + v] = X.sq[lane][v]; }
-                SmplxSState ns;
-                ns.h = (unsigned int)X.h[lane];
-                sstate_reinit(ns, W.call_number);
-                sstate_store(&P->st[id], ns, true);
-                P->done_off[id] = -1;
-                fresh_h = ns.h;
-            }
-            unsigned long long m_clash = __ballot(clash);
-            while (m_clash) {      // uniform loop: one clashing lane at a time probes behind what the others have stored
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                const int j = __ffsll((long long)m_clash) - 1;
-                m_clash &= m_clash - 1;
-                if (lane == j) {
-                    const TableProbe pr = table_probe_own(table, (const LDS_AS int*)X.coord[lane], nv, hash);
-                    table_store_own(table, pr.free_slot, (const LDS_AS int*)X.coord[lane], nv, id);
-                }
-            }
-            const int id_of_dup = __shfl(id, dup_of >= 0 ? dup_of : 0);
-            if (dup_of >= 0) id = id_of_dup;
-            fresh = is_new || dup_of >= 0;
-            if (dup_of >= 0) fresh_h = (unsigned int)X.h[dup_of];
-            cnt = __popcll(m_valid);
-            if (valid) {
-                k = __popcll(m_valid & below);
-                sid = (flags & SMPLX_F_GOAL) ? 0 : id;      // a goal successor is reported as the goal id (manip_lattice.cpp:283-296)
-                if (flags & SMPLX_F_GOAL) fresh = false;
-                W.succ_id[k] = sid;
-                W.succ_cost[k] = A.cost[lane];
-                SmplxSucc sc;
-                sc.id = sid;
-                sc.cost_prim = A.cost[lane] | (lane << 24);
-                P->succ[W.n_succ + k] = sc;
-            }
+            // =========================== expand state m (arastar.cpp:513-519, 531-568) ===========================
+            // ---- pop (intrusive_heap.hpp:155-166).  The state popped is very often one the previous relaxation has just
+            // stored (another lane of this wave did): those stores have landed before it is read ----
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            const SmplxSState sm = sstate_load(&P->st[m]);           // g, h: in flight together with the loads below
+            const hent_t last = hget(H, R.heap_size);
+            const int off = P->done_off[m];                          // >= 0: expanded before (a later ARA* iteration)
+            const int dcnt = P->done_cnt[m];
+            if (lane < nv) X.parent[lane] = P->q[(size_t)m * nv + lane];
+            if (lane < nprims) { X.edge_bad[lane] = 0; X.edge_lk[lane] = 0; }
+            if (lane == 0) { X.state_bad = 0; X.state_lookups = 0; P->st[m].heap_index = 0; }
+            --R.heap_size;
+            if (R.heap_size >= 1) heap_sift_down_wave(H, lane, 1, R.heap_size, last);
+            const unsigned int eg = sm.g;
             if (lane == 0) {
-                const int evals = __popcll(m_eval);
-                P->done_off[m] = W.n_succ;
-                P->done_cnt[m] = cnt | (evals << 8);
-                W.n_succ += cnt;
-                W.nstates += __popcll(m_new);
-                W.cnt = cnt; W.evals = evals;
-                W.gpu_evals += evals;
+                *reinterpret_cast<unsigned int*>(&P->st[m].iteration_closed) = ((unsigned int)R.iteration & 0xFFFFu) | ((unsigned int)sm.call_number << 16);
+                P->st[m].eg = eg;
+                P->log[R.n_log] = m;
             }
-            // (grid lookups of this expansion, as the reference would count them)
-            int lk = in ? X.lookups[lane] : 0;
-            for (int o = 32; o > 0; o >>= 1) lk += __shfl_down(lk, o);
-            if (lane == 0) W.lookups += lk;
-        }
-        // which successors name the same state (two goal successors; a primitive that lands in its parent's cell)
-        int alias = -1;
-        {
-            const unsigned long long m_valid = __ballot(valid);
-            for (int j = 0; j < 64; ++j) {
-                if (!((m_valid >> j) & 1ull)) continue;      // uniform
-                const int sj = __shfl(sid, j), kj = __shfl(k, j);
-                if (valid && j < lane && alias < 0 && sj == sid) alias = kj;
-            }
-        }
-        if (valid) {
-            W.alias[k] = alias;
-            if (fresh && alias < 0) {
-                SmplxSState ns;                                 // what this expansion has just stored for the new state
-                ns.h = fresh_h;
-                sstate_reinit(ns, W.call_number);
-                W.sst[k] = ns;
-            } else if (alias < 0) {
-                W.sst[k] = P->st[sid];
-            }
-        }
-        {
-            // ancestors of the slots n + 1 .. n + cnt (where this relaxation's pushes go) that lie beyond the LDS part
-            const int n = W.heap_size;
-            int nlev = 0, total = 0;
-            int my_idx[2] = {-1, -1}, my_slot[2] = {0, 0};
-            for (int j = 1; j <= SMPLX_AC_LEVELS; ++j) {
-                int lo = (n + 1) >> j, hi = (n + cnt) >> j;
-                if (hi > n) hi = n;
-                if (hi < H.lh || cnt == 0) break;
-                if (lo < H.lh) lo = H.lh;
-                const int len = hi - lo + 1;
-                if (total + len > SMPLX_AC_SLOTS) break;
-                if (lane == 0) { W.ac_lo[j] = lo; W.ac_hi[j] = hi; W.ac_base[j] = total; }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int e = lane + 64 * r - total;
-                    if (e >= 0 && e < len) { my_idx[r] = lo + e; my_slot[r] = lane + 64 * r; }
+            ++R.n_log;
+            SK_TICK(1);
+
+            // per-lane data of this step: lane p < nprims = primitive p (evaluation), lane k < cnt = list entry k (cached)
+            bool valid = false;
+            int sid = -1, cost = 0, cnt = 0, evals = 0;
+            SmplxSState ss;                                          // the successor's search state
+            ss.g = ss.h = ss.f = ss.eg = 0; ss.bp = -1; ss.heap_index = 0; ss.iteration_closed = 0; ss.call_number = 0; ss.flags = 0;
+
+            if (off < 0) {
+                // ---- GetSuccs loop body (manip_lattice.cpp:254-305): successors' joint values, then the waypoint lanes ----
+                SMPLX_WAVE_SYNC();                                   // X.parent is complete
+                double gd;
+                if (gd_from_h) {
+                    const int hh = (int)sm.h;
+                    gd = hh == 32767 ? (double)0x7FFFFFFF * grid.res : (double)(hh / cpc) * grid.res;
+                } else {
+                    double g1 = 0.0;
+                    if (lane == 0) g1 = expand_goal_distance(M, grid, bfs, X);
+                    const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
+                    gd = __longlong_as_double((long long)bits);
                 }
-                total += len;
-                nlev = j;
-            }
-            if (lane == 0) W.ac_nlev = nlev;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                if (my_idx[r] >= 0) W.ac_val[my_slot[r]] = H.hbm[my_idx[r]];
-        }
-        SMPLX_WAVE_SYNC();
-        if (t == 0) {
-            SK_TICK(3);
-            // ---- ARAStar::expand's loop over the successors, in primitive order (arastar.cpp:540-567) ----
-            W.committed_evals += W.evals;
-            const unsigned int eg = W.eg;
-            const int n_succ = W.cnt;
-            for (int i = 0; i < n_succ; ++i) {
-                const int id = W.succ_id[i];
-                const int al = W.alias[i];
-                SmplxSState& ss = W.sst[al >= 0 ? al : i];
-                bool dirty = false;
-                if (ss.call_number != (unsigned short)W.call_number) { sstate_reinit(ss, W.call_number); P->st[id].heap_index = 0; dirty = true; }
-                const int new_cost = (int)(eg + (unsigned int)W.succ_cost[i]);
-                if ((unsigned int)new_cost < ss.g) {
-                    const bool reached_before = ss.g != SMPLX_INFINITECOST;
-                    ss.g = (unsigned int)new_cost;
-                    ss.bp = m;
-                    dirty = true;
-                    if (ss.iteration_closed != (unsigned short)W.iteration) {
-                        ss.f = search_key(W.curr_eps, ss.g, ss.h);
-                        if (id == 0) W.goal_f = ss.f;
-                        // a state reached for the first time in this call is not in OPEN; otherwise its position is read
-                        // where the sifts keep it current
-                        const int hi = reached_before ? P->st[id].heap_index : 0;
-                        if (hi != 0) {
-                            const hent_t e = hent_make(ss.f, id);
-                            if (hi < H.lh) H.lds[hi] = e; else { H.hbm[hi] = e; ac_update(W, hi, e); }
-                            if (ss.flags & 1u) heap_refresh_duplicates_r(H, W, W.heap_size, id, ss.f);
-                            heap_percolate_up_r(H, W, hi);
-                        } else {
-                            if ((ss.flags & 1u) && W.dup_pushes > 0) heap_refresh_duplicates_r(H, W, W.heap_size, id, ss.f);
-                            ++W.heap_size;
-                            heap_push_r(H, W, W.heap_size, hent_make(ss.f, id));
-                        }
-                    } else {
-                        P->incons[W.n_incons++] = id;      // (never marked: arastar.cpp:563-565)
+                const bool in = lane < nprims;
+                const bool act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd, A.type[lane]);
+                if (act) expand_successor_values(M, A, Sq, X, lane);
+                if (lane == 0) { X.goal_dist = gd; W.action = SA_EVAL; }
+                __syncthreads();                                     // A
+                BookLane b;
+                b.limits_ok = false; b.W = 0; b.h = 0; b.is_goal = 0;
+                unsigned int hash = 0;
+                TableProbe pr;
+                pr.id = -1; pr.free_slot = 0;
+                if (act) {
+                    expand_book_coords(M, X, lane, b);
+                    if (b.limits_ok) {
+                        // getHashEntry (manip_lattice.cpp:1302-1316): the home slot's loads travel behind the planning-link FK;
+                        // a coordinate the table knows has its search state requested at once (it lands behind the waypoint lanes)
+                        hash = coord_hash_lds((const LDS_AS int*)X.coord[lane], nv);
+                        TableProbeLoads ld = table_probe_start(table, nv, hash);
+                        expand_book_goal(M, grid, bfs, Sq, X, lane, b);
+                        pr = table_probe_finish(table, ld, (const LDS_AS int*)X.coord[lane], nv);
+                        if (pr.id >= 0 && !b.is_goal) ss = sstate_load(&P->st[pr.id]);
                     }
                 }
-                if (dirty) sstate_store(&P->st[id], ss, false);
+                const SmplxSState goal_ss = sstate_load(&P->st[0]);   // (a goal successor relaxes the goal state)
+                __syncthreads();                                     // B: the waypoint verdicts have landed
+                SK_TICK(2);
+                int lookups = 0;
+                const int flags = in ? expand_verdict(A, X, lane, act, b, lookups) : SMPLX_F_INACTIVE;
+                valid = (flags & SMPLX_F_VALID) != 0;
+                const bool goal_succ = valid && (flags & SMPLX_F_GOAL) != 0;
+                int id = pr.id;
+                // ---- getOrCreateState (manip_lattice.cpp:1318-1354).  Two successors of this expansion with the same new
+                // coordinate: the lower primitive creates the state ----
+                const bool unknown = valid && id < 0;
+                const unsigned long long m_unknown = __ballot(unknown);
+                int dup_of = -1;
+                {
+                    unsigned long long rest = m_unknown;
+                    while (rest) {                                   // uniform
+                        const int j = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1;
+                        const unsigned int hj = wave_rlu(hash, j);
+                        if (j < lane && unknown && dup_of < 0 && hj == hash) {
+                            bool same = true;
+                            for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
+                            if (same) dup_of = j;
+                        }
+                    }
+                }
+                const bool is_new = unknown && dup_of < 0;
+                const unsigned long long m_new = __ballot(is_new), m_valid = __ballot(valid), m_eval = __ballot(in && !(flags & SMPLX_F_INACTIVE));
+                // two new coordinates whose probing ended at the same empty slot (rare): the later one probes again below
+                bool clash = false;
+                {
+                    unsigned long long rest = m_new;
+                    while (rest) {
+                        const int j = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1;
+                        const unsigned int fj = wave_rlu(pr.free_slot, j);
+                        if (j < lane && is_new && fj == pr.free_slot) clash = true;
+                    }
+                }
+                if (is_new) {
+                    id = R.nstates + __popcll(m_new & below);
+                    if (!clash) table_store_own(table, pr.free_slot, (const LDS_AS int*)X.coord[lane], nv, id);
+                    for (int v = 0; v < nv; ++v) { P->coord[(size_t)id * nv + v] = X.coord[lane][v]; P->q[(size_t)id * nv + v] = X.sq[lane][v]; }
+                    ss.h = (unsigned int)b.h;
+                    sstate_reinit(ss, R.call_number);
+                    sstate_store(&P->st[id], ss, true);              // (what the relaxation changes is stored again behind it)
+                    P->done_off[id] = -1;
+                }
+                {
+                    unsigned long long m_clash = __ballot(clash);
+                    while (m_clash) {      // uniform loop: one clashing lane at a time probes behind what the others have stored
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        const int j = __ffsll((long long)m_clash) - 1;
+                        m_clash &= m_clash - 1;
+                        if (lane == j) {
+                            TableProbeLoads ld = table_probe_start(table, nv, hash);
+                            const TableProbe p2 = table_probe_finish(table, ld, (const LDS_AS int*)X.coord[lane], nv);
+                            table_store_own(table, p2.free_slot, (const LDS_AS int*)X.coord[lane], nv, id);
+                        }
+                    }
+                }
+                {
+                    const int id_of_dup = __shfl(id, dup_of >= 0 ? dup_of : lane);
+                    if (dup_of >= 0) id = id_of_dup;
+                }
+                cnt = __popcll(m_valid);
+                evals = __popcll(m_eval);
+                if (valid) {
+                    sid = goal_succ ? 0 : id;      // a goal successor is reported as the goal id (manip_lattice.cpp:283-296)
+                    cost = A.cost[lane];
+                    if (goal_succ) ss = goal_ss;
+                    SmplxSucc sc;
+                    sc.id = sid;
+                    sc.cost_prim = cost | (lane << 24);
+                    P->succ[R.n_succ + __popcll(m_valid & below)] = sc;
+                }
+                if (lane == 0) { P->done_off[m] = R.n_succ; P->done_cnt[m] = cnt | (evals << 8); }
+                R.n_succ += cnt;
+                R.nstates += __popcll(m_new);
+                R.gpu_evals += evals;
+                {
+                    int lk = in ? lookups : 0;       // grid lookups of this expansion, as the reference would count them
+                    for (int o = 32; o > 0; o >>= 1) lk += __shfl_down(lk, o);
+                    R.lookups += wave_rl(lk, 0);
+                }
+            } else {
+                // ---- GetSuccs of a state expanded before: the committed list ----
+                if (lane == 0) W.action = SA_SKIP;
+                __syncthreads();                                     // A
+                cnt = dcnt & 0xFF;
+                evals = dcnt >> 8;
+                valid = lane < cnt;
+                if (valid) {
+                    const SmplxSucc sc = P->succ[off + lane];
+                    sid = sc.id;
+                    cost = sc.cost_prim & 0xFFFFFF;
+                    ss = sstate_load(&P->st[sid]);
+                }
+                __syncthreads();                                     // B
+                SK_TICK(2);
             }
-            W.ac_nlev = 0;
-            ++W.num;
-            SK_TICK(4);
-            select();
-            SK_TICK(1);
-        }
-    }
 
-    // ---- the launch ends: results, or the state the next launch picks up ----
+            // ---- which successors name the same state (two goal successors; a primitive that lands in an earlier one's
+            // cell): the earliest lane keeps the state, the others refer to it ----
+            const unsigned long long m_succ = __ballot(valid);
+            bool ac_complete = true;     // the ancestor cache holds every HBM-resident ancestor the pushes will read
+            int alias = -1;
+            {
+                unsigned long long rest = m_succ;
+                while (rest) {
+                    const int j = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int sj = wave_rl(sid, j);
+                    if (valid && j < lane && alias < 0 && sj == sid) alias = j;
+                }
+            }
+            // ---- ancestors of the slots n + 1 .. n + cnt (where this relaxation's pushes go) that lie beyond the LDS part of
+            // the heap: one round trip, all lanes ----
+            {
+                const int n = R.heap_size;
+                int nlev = 0, total = 0;
+                int my_idx[2] = {-1, -1};
+                ac_complete = true;
+                for (int j = 1; j <= SMPLX_AC_LEVELS; ++j) {
+                    int lo = (n + 1) >> j, hi = (n + cnt) >> j;
+                    if (hi > n) hi = n;
+                    if (hi < H.lh || cnt == 0) break;
+                    if (lo < H.lh) lo = H.lh;
+                    const int len = hi - lo + 1;
+                    if (total + len > SMPLX_AC_SLOTS || j == SMPLX_AC_LEVELS) { ac_complete = false; break; }
+                    if (lane == 0) { W.ac_lo[j] = lo; W.ac_hi[j] = hi; W.ac_base[j] = total; }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int e = lane + 64 * r - total;
+                        if (e >= 0 && e < len) my_idx[r] = lo + e;
+                    }
+                    total += len;
+                    nlev = j;
+                }
+                if (lane == 0) W.ac_nlev = nlev;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (my_idx[r] >= 0) W.ac_val[lane + 64 * r] = H.hbm[my_idx[r]];
+            }
+            // what earlier lanes of this wave stored (heap entries moved by the pop, the popped state's closing, new states'
+            // rows) and others read below (a self-loop successor, the ancestor cache) has landed
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            SK_TICK(3);
+
+            // ---- ARAStar::expand's loop over the successors, in primitive order (arastar.cpp:540-567): uniform control
+            // flow, the state of successor j in the registers of lane j ----
+            R.committed_evals += evals;
+            bool dirty = false;
+            {
+                unsigned long long rest = m_succ;
+                while (rest) {
+                    const int j = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int aj = wave_rl(alias, j);
+                    const int r = aj >= 0 ? aj : j;                  // the lane that keeps this successor's state
+                    const int id = wave_rl(sid, j);
+                    const int cj = wave_rl(cost, j);
+                    unsigned int g_r = wave_rlu(ss.g, r);
+                    const unsigned int h_r = wave_rlu(ss.h, r);
+                    unsigned int itc_r = (unsigned int)wave_rl((int)ss.iteration_closed | ((int)ss.call_number << 16), r);
+                    unsigned int flags_r = wave_rlu(ss.flags, r);
+                    if ((itc_r >> 16) != (unsigned int)R.call_number) {
+                        // reinitSearchState: not touched in this call (and so not in OPEN)
+                        if (lane == r) { sstate_reinit(ss, R.call_number); dirty = true; }
+                        if (lane == 0) P->st[id].heap_index = 0;
+                        g_r = SMPLX_INFINITECOST; itc_r = (unsigned int)R.call_number << 16; flags_r = 0;
+                    }
+                    const int new_cost = (int)(eg + (unsigned int)cj);
+                    if (!((unsigned int)new_cost < g_r)) continue;
+                    const bool reached_before = g_r != SMPLX_INFINITECOST;
+                    if (lane == r) { ss.g = (unsigned int)new_cost; ss.bp = m; dirty = true; }
+                    if ((itc_r & 0xFFFFu) != ((unsigned int)R.iteration & 0xFFFFu)) {
+                        const unsigned int f = search_key(R.curr_eps, (unsigned int)new_cost, h_r);
+                        if (lane == r) ss.f = f;
+                        if (id == 0) R.goal_f = f;
+                        // a state reached for the first time in this call is not in OPEN; otherwise its position is read where
+                        // the sifts keep it current
+                        int hi = 0;
+                        if (reached_before || !ac_complete) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // earlier sifts' stores have landed
+                        if (reached_before) hi = P->st[id].heap_index;
+                        const hent_t e = hent_make(f, id);
+                        if (hi != 0) {
+                            if (flags_r & 1u) heap_refresh_duplicates_wave(H, W, lane, R.heap_size, id, f);
+                            heap_sift_up_wave(H, W, lane, hi, e, false);
+                        } else {
+                            if ((flags_r & 1u) && R.dup_pushes > 0) heap_refresh_duplicates_wave(H, W, lane, R.heap_size, id, f);
+                            ++R.heap_size;
+                            heap_sift_up_wave(H, W, lane, R.heap_size, e, true);
+                        }
+                    } else {
+                        if (lane == 0) P->incons[R.n_incons] = id;      // (never marked: arastar.cpp:563-565)
+                        ++R.n_incons;
+                    }
+                }
+            }
+            if (dirty && valid && alias < 0) sstate_store(&P->st[sid], ss, false);
+            if (lane == 0) W.ac_nlev = 0;
+            ++R.num;
+            SK_TICK(4);
+        }
+
+        // ---- the launch ends: results, or the state the next launch picks up ----
+        if (lane == 0) {
+            int solved = Ph.solved, cost = Ph.cost, n_path = Ph.n_path;
+            if (R.phase == 3) {
+                // arastar.cpp:199-214
+                R.expand_count += R.num;
+                R.status = SMPLX_SS_DONE;
+                if (R.satisfied_eps == __builtin_inf()) {
+                    solved = 0; cost = 0; n_path = 0;
+                } else {
+                    int n = 0;
+                    for (int sid = 0; sid >= 0 && n < P->cap_path; sid = P->st[sid].bp) P->path[n++] = sid;
+                    n_path = n;
+                    cost = (int)P->st[0].g;
+                    solved = 1;
+                }
+                R.phase = 4;
+            }
+            Pd->solved = solved; Pd->cost = cost; Pd->n_path = n_path;
+            Pd->curr_eps = R.curr_eps; Pd->satisfied_eps = R.satisfied_eps;
+            Pd->heap_size = R.heap_size; Pd->nstates = R.nstates; Pd->n_incons = R.n_incons; Pd->n_log = R.n_log; Pd->n_succ = R.n_succ;
+            Pd->iteration = R.iteration; Pd->call_number = R.call_number; Pd->phase = R.phase; Pd->num = R.num;
+            Pd->expand_count = R.expand_count; Pd->expand_count_init = R.expand_count_init; Pd->err = R.err;
+            Pd->dup_pushes = R.dup_pushes; Pd->goal_f = R.goal_f;
+            Pd->status = R.status; Pd->grow_what = R.grow_what;
+            Pd->committed_evals = R.committed_evals; Pd->gpu_evals = R.gpu_evals; Pd->lookups = R.lookups;
+            SK_TICK(6);
+            for (int k = 0; k < 8; ++k) Pd->ticks[k] = ticks[k];
+            if (status_out) status_out[blockIdx.x] = R.status;
+            W.reorder_size = R.heap_size;                           // (for the write-back of the LDS part below)
+        }
+#undef SK_TICK
+    }
     __syncthreads();
     {
-        const int n = W.heap_size + 1 < lh ? W.heap_size + 1 : lh;
+        const int n = W.reorder_size + 1 < lh ? W.reorder_size + 1 : lh;
         for (int i = t; i < n; i += blockDim.x) H.hbm[i] = H.lds[i];
     }
-    if (t == 0) {
-        int solved = Ph.solved, cost = Ph.cost, n_path = Ph.n_path;
-        if (W.phase == 3) {
-            // arastar.cpp:199-214
-            W.expand_count += W.num;
-            W.status = SMPLX_SS_DONE;
-            if (W.satisfied_eps == __builtin_inf()) {
-                solved = 0; cost = 0; n_path = 0;
-            } else {
-                int n = 0;
-                for (int sid = 0; sid >= 0 && n < P->cap_path; sid = P->st[sid].bp) P->path[n++] = sid;
-                n_path = n;
-                cost = (int)P->st[0].g;
-                solved = 1;
-            }
-            W.phase = 4;
-        }
-        Pd->solved = solved; Pd->cost = cost; Pd->n_path = n_path;
-        Pd->curr_eps = W.curr_eps; Pd->satisfied_eps = W.satisfied_eps;
-        Pd->heap_size = W.heap_size; Pd->nstates = W.nstates; Pd->n_incons = W.n_incons; Pd->n_log = W.n_log; Pd->n_succ = W.n_succ;
-        Pd->iteration = W.iteration; Pd->call_number = W.call_number; Pd->phase = W.phase; Pd->num = W.num;
-        Pd->expand_count = W.expand_count; Pd->expand_count_init = W.expand_count_init; Pd->err = W.err;
-        Pd->dup_pushes = W.dup_pushes; Pd->goal_f = W.goal_f;
-        Pd->status = W.status; Pd->grow_what = W.grow_what;
-        Pd->committed_evals = W.committed_evals; Pd->gpu_evals = W.gpu_evals; Pd->lookups = W.lookups;
-        SK_TICK(6);
-        for (int k = 0; k < 8; ++k) Pd->ticks[k] = W.ticks[k];
-        if (status_out) status_out[blockIdx.x] = W.status;
-    }
-#undef SK_TICK
 }
 
 // getOrCreateState for states the device table does not hold yet (the start state the host created; every state after
@@ -840,65 +887,59 @@ k_search_table_fill(const SmplxSpaceDev* __restrict__ Sq, const int* __restrict_
 // Parity-test kernel (test_hooks.h): the heap primitives of k_search driven by an op sequence in the language of
 // oracle/heap_ref_driver.cpp -- 0 push(priority), 1 pop, 2 / 5 decrease / increase(element << 20 | priority), 3 erase(element),
 // 4 re-prioritise everything and make() -- so that they can be compared with the reference's own intrusive_heap
-// (tests/golden/heap_ref.json).  Element e is state e; the first `lh` heap entries live in LDS, the rest in HBM.
-extern "C" __global__ void __launch_bounds__(256)
+// (tests/golden/heap_ref.json).  Element e is state e; the first `lh` heap entries live in LDS, the rest in HBM.  One wave:
+// push / decrease run the wave-parallel sift-up, pop / increase / erase the wave-parallel sift-down, make() the level-parallel
+// form -- the code paths of the search.
+extern "C" __global__ void __launch_bounds__(64)
 k_heap_ops(const int* __restrict__ ops, int nops, int lh, unsigned long long* __restrict__ heap_hbm, SmplxSState* __restrict__ st,
            int* __restrict__ top_after)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int s_size, s_make;
+    __shared__ SearchLds W;
     HeapRef H;
     H.lds = (LDS_AS hent_t*)smem;
     H.hbm = heap_hbm;
     H.st = st;
     H.lh = lh;
-    const int t = threadIdx.x;
-    if (t == 0) { s_size = 0; s_make = 0; }
+    const int lane = threadIdx.x;
+    if (lane == 0) W.ac_nlev = 0;
     __syncthreads();
-    int nelem = 0;
+    int nelem = 0, size = 0;
     for (int i = 0; i < nops; ++i) {
         const int code = ops[2 * i], key = ops[2 * i + 1];
-        if (t == 0) {
-            int size = s_size;
-            if (code == 0) {
-                st[nelem].f = (unsigned int)key;
-                st[nelem].heap_index = 0;
-                ++size;
-                hset(H, size, hent_make((unsigned int)key, nelem));
-                heap_percolate_up(H, size);
-            } else if (code == 1) {
-                if (size > 0) {
-                    st[hent_id(hget(H, 1))].heap_index = 0;
-                    const hent_t last = hget(H, size);
-                    --size;
-                    if (size >= 1) { hput(H, 1, last); heap_percolate_down(H, 1, size); }
-                }
-            } else if (code == 2 || code == 5) {
-                const int e = key >> 20, p = key & 0xFFFFF;
-                if (e < nelem && st[e].heap_index != 0) {
-                    const int hi = st[e].heap_index;
-                    st[e].f = (unsigned int)p;
-                    hput(H, hi, hent_make((unsigned int)p, e));
-                    if (code == 2) heap_percolate_up(H, hi); else heap_percolate_down(H, hi, size);
-                }
-            } else if (code == 3) {
-                if (key < nelem && st[key].heap_index != 0) {      // intrusive_heap.hpp:197-206
-                    const int pos = st[key].heap_index;
-                    const hent_t last = hget(H, size);
-                    hset(H, pos, last);
-                    st[key].heap_index = 0;
-                    --size;
-                    heap_percolate_down(H, pos, size);
-                }
+        if (code == 0) {
+            if (lane == 0) { st[nelem].f = (unsigned int)key; st[nelem].heap_index = 0; }
+            ++size;
+            heap_sift_up_wave(H, W, lane, size, hent_make((unsigned int)key, nelem), false);
+            ++nelem;
+        } else if (code == 1) {
+            if (size > 0) {
+                const hent_t top = hget(H, 1), last = hget(H, size);
+                if (lane == 0) st[hent_id(top)].heap_index = 0;
+                --size;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (size >= 1) heap_sift_down_wave(H, lane, 1, size, last);
             }
-            s_size = size;
-            s_make = code == 4;
-        }
-        if (code == 0) ++nelem;
-        __syncthreads();
-        if (s_make) {
-            const int size = s_size;
-            for (int k = 1 + t; k <= size; k += blockDim.x) {
+        } else if (code == 2 || code == 5) {
+            const int e = key >> 20, p = key & 0xFFFFF;
+            const int hi = e < nelem ? st[e].heap_index : 0;
+            if (hi != 0) {
+                if (lane == 0) st[e].f = (unsigned int)p;
+                if (code == 2) heap_sift_up_wave(H, W, lane, hi, hent_make((unsigned int)p, e), false);
+                else heap_sift_down_wave(H, lane, hi, size, hent_make((unsigned int)p, e));
+            }
+        } else if (code == 3) {
+            const int pos = key < nelem ? st[key].heap_index : 0;
+            if (pos != 0) {                                      // intrusive_heap.hpp:197-206
+                const hent_t last = hget(H, size);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (lane == 0) { hset(H, pos, last); st[key].heap_index = 0; }
+                --size;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (pos <= size) heap_sift_down_wave(H, lane, pos, size, last);
+            }
+        } else if (code == 4) {
+            for (int k = 1 + lane; k <= size; k += 64) {
                 const int e = hent_id(hget(H, k));
                 const unsigned int p = (st[e].f * 7919u + 13u) % 1000u;
                 st[e].f = p;
@@ -907,7 +948,7 @@ k_heap_ops(const int* __restrict__ ops, int nops, int lh, unsigned long long* __
             __syncthreads();
             heap_make_block(H, size, false);
         }
-        if (t == 0) top_after[i] = s_size > 0 ? hent_id(hget(H, 1)) : -1;
-        __syncthreads();
+        __syncthreads();      // (one wave: orders what the lanes stored with what the next op reads)
+        if (lane == 0) top_after[i] = size > 0 ? hent_id(hget(H, 1)) : -1;
     }
 }
