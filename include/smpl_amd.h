@@ -289,13 +289,15 @@ typedef struct smplx_search_stats {
 } smplx_search_stats;
 
 /* ARAStar::replan from scratch (arastar.cpp:107-215) on the query of `s`.
- * Where the search runs.  By default ON THE DEVICE: one persistent workgroup owns the query -- OPEN (the
+ * Where the search runs.  Two or more queries (smplx_plan_multi), or env SMPLX_SEARCH=device: ON THE DEVICE (SURVEY row
+ * N2): one persistent workgroup owns a query -- OPEN (the
  * reference's binary heap with its sift rules, intrusive_heap.hpp:346-395), INCONS, the state table and the search
  * states live in HBM, the workgroup pops a state, evaluates its successors on its lanes, creates states with ids in its
  * own commit order (= the reference's ids) and pushes them; the host only launches, enlarges buffers when asked, and
  * reads results (stats: gpu_batches = kernel launches, cache_misses = 0).  The lattice stays in HBM until an entry point
  * needs it on the host (smplx_get_state, smplx_expansion_log, smplx_get_succs ...), which then see every state the
- * device created.  Robots whose expansion does not fit one workgroup's LDS, spaces created with SMPLX_SPACE_FUSED /
+ * device created.  A single query (it is a chain of dependent expansions: the host loop's speculative batches are the
+ * faster way to run one), robots whose expansion does not fit one workgroup's LDS, spaces created with SMPLX_SPACE_FUSED /
  * SMPLX_SPACE_NO_SMALL_KERNEL, and env SMPLX_SEARCH=host take the host-driven loop instead: the same sequential ARA*
  * on the host with frontier batches on the GPU (what an external SBPL planner gets through smplx_get_succs).  Results
  * are identical either way. */

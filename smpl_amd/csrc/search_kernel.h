@@ -168,8 +168,25 @@ __device__ __forceinline__ void heap_sift_up_wave(const HeapRef& H, SearchLds& W
     }
     const unsigned long long m_anc = __ballot(anc), m_stop = __ballot(anc && hent_f(ent) < hent_f(e));
     const int jstop = m_stop ? __ffsll((long long)m_stop) - 1 : __popcll(m_anc) + 1;   // ancestors are lanes 1 .. popc(m_anc)
-    if (anc && j < jstop) hset_ac(H, W, start >> (j - 1), ent);
-    if (j == 0) hset_ac(H, W, start >> (jstop - 1), e);
+    if (!cached) {
+        if (anc && j < jstop) hset_ac(H, W, start >> (j - 1), ent);
+        if (j == 0) hset_ac(H, W, start >> (jstop - 1), e);
+        return;
+    }
+    // a walk the cache was built for: a write to level l of the walk can only concern the cache's level l (level 0, the new
+    // slots themselves, is not cached)
+    const bool mover = anc && j < jstop;
+    if (mover || j == 0) {
+        const int l = mover ? j - 1 : jstop - 1;
+        const int dst = start >> l;
+        const hent_t v = mover ? ent : e;
+        if (dst < H.lh) H.lds[dst] = v;
+        else {
+            H.hbm[dst] = v;
+            if (l >= 1 && l <= W.ac_nlev && dst >= W.ac_lo[l] && dst <= W.ac_hi[l]) W.ac_val[W.ac_base[l] + dst - W.ac_lo[l]] = v;
+        }
+        H.st[hent_id(v)].heap_index = dst;
+    }
 }
 
 // percolate_down by the whole wave (intrusive_heap.hpp:346-377): entry tmp sifts down from `pivot`.  Lanes 0 .. 61 fetch the
@@ -323,6 +340,36 @@ __device__ __forceinline__ void table_store_own(const SmplxTableDev& T, unsigned
     int* sl = T.slots + (size_t)slot * T.stride;
     for (int v = 0; v < nv; ++v) sl[1 + v] = c[v];
     sl[0] = id + 1;
+}
+
+// Ancestors of the slots n + 1 .. n + cnt (where a relaxation's pushes go) that lie beyond the LDS part of the heap: one
+// round trip, all lanes of the search wave.  Returns whether every such ancestor fits the cache.
+__device__ __forceinline__ bool ancestor_cache_fill(const HeapRef& H, SearchLds& W, int lane, int n, int cnt)
+{
+    int nlev = 0, total = 0;
+    int my_idx[2] = {-1, -1};
+    bool complete = true;
+    for (int j = 1; j <= SMPLX_AC_LEVELS; ++j) {
+        int lo = (n + 1) >> j, hi = (n + cnt) >> j;
+        if (hi > n) hi = n;
+        if (hi < H.lh || cnt == 0) break;
+        if (lo < H.lh) lo = H.lh;
+        const int len = hi - lo + 1;
+        if (total + len > SMPLX_AC_SLOTS || j == SMPLX_AC_LEVELS) { complete = false; break; }
+        if (lane == 0) { W.ac_lo[j] = lo; W.ac_hi[j] = hi; W.ac_base[j] = total; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = lane + 64 * r - total;
+            if (e >= 0 && e < len) my_idx[r] = lo + e;
+        }
+        total += len;
+        nlev = j;
+    }
+    if (lane == 0) W.ac_nlev = nlev;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (my_idx[r] >= 0) W.ac_val[lane + 64 * r] = H.hbm[my_idx[r]];
+    return complete;
 }
 
 // the search's variables: registers of the search wave, the same value in every lane
@@ -576,6 +623,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
 
             // per-lane data of this step: lane p < nprims = primitive p (evaluation), lane k < cnt = list entry k (cached)
             bool valid = false;
+            bool ac_complete = true;     // the ancestor cache holds every HBM-resident ancestor the pushes will read
             int sid = -1, cost = 0, cnt = 0, evals = 0;
             SmplxSState ss;                                          // the successor's search state
             ss.g = ss.h = ss.f = ss.eg = 0; ss.bp = -1; ss.heap_index = 0; ss.iteration_closed = 0; ss.call_number = 0; ss.flags = 0;
@@ -616,6 +664,38 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     }
                 }
                 const SmplxSState goal_ss = sstate_load(&P->st[0]);   // (a goal successor relaxes the goal state)
+                // While the waypoint lanes work: everything of getOrCreateState that does not need their verdict.  Among the
+                // CANDIDATES (edges within limits) -- two with the same unknown coordinate (the lower primitive creates the
+                // state), two whose probing ended at the same empty slot -- and the heap's ancestors for the pushes to come.
+                const bool cand = act && b.limits_ok;
+                const bool c_unknown = cand && pr.id < 0;
+                auto find_dups = [&](bool mine, unsigned long long members) {
+                    int d = -1;
+                    while (members) {                                // uniform
+                        const int j = __ffsll((long long)members) - 1;
+                        members &= members - 1;
+                        const unsigned int hj = wave_rlu(hash, j);
+                        if (j < lane && mine && d < 0 && hj == hash) {
+                            bool same = true;
+                            for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
+                            if (same) d = j;
+                        }
+                    }
+                    return d;
+                };
+                auto find_clash = [&](bool mine, unsigned long long members) {
+                    bool c = false;
+                    while (members) {
+                        const int j = __ffsll((long long)members) - 1;
+                        members &= members - 1;
+                        const unsigned int fj = wave_rlu(pr.free_slot, j);
+                        if (j < lane && mine && fj == pr.free_slot) c = true;
+                    }
+                    return c;
+                };
+                int dup_of = find_dups(c_unknown, __ballot(c_unknown));
+                bool clash = find_clash(c_unknown && dup_of < 0, __ballot(c_unknown && dup_of < 0));
+                ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, __popcll(__ballot(cand)));
                 __syncthreads();                                     // B: the waypoint verdicts have landed
                 SK_TICK(2);
                 int lookups = 0;
@@ -623,37 +703,21 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 valid = (flags & SMPLX_F_VALID) != 0;
                 const bool goal_succ = valid && (flags & SMPLX_F_GOAL) != 0;
                 int id = pr.id;
-                // ---- getOrCreateState (manip_lattice.cpp:1318-1354).  Two successors of this expansion with the same new
-                // coordinate: the lower primitive creates the state ----
+                // ---- getOrCreateState (manip_lattice.cpp:1318-1354) ----
                 const bool unknown = valid && id < 0;
-                const unsigned long long m_unknown = __ballot(unknown);
-                int dup_of = -1;
+                if (!unknown) dup_of = -1;
                 {
-                    unsigned long long rest = m_unknown;
-                    while (rest) {                                   // uniform
-                        const int j = __ffsll((long long)rest) - 1;
-                        rest &= rest - 1;
-                        const unsigned int hj = wave_rlu(hash, j);
-                        if (j < lane && unknown && dup_of < 0 && hj == hash) {
-                            bool same = true;
-                            for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
-                            if (same) dup_of = j;
-                        }
+                    // a candidate that was to create the state for a later one turned out to collide (rare): the pairs again,
+                    // among the valid successors only
+                    const bool root_valid = __shfl((int)valid, dup_of >= 0 ? dup_of : lane) != 0;
+                    if (__ballot(unknown && dup_of >= 0 && !root_valid)) {
+                        dup_of = find_dups(unknown, __ballot(unknown));
+                        clash = find_clash(unknown && dup_of < 0, __ballot(unknown && dup_of < 0));
                     }
                 }
                 const bool is_new = unknown && dup_of < 0;
+                if (!is_new) clash = false;
                 const unsigned long long m_new = __ballot(is_new), m_valid = __ballot(valid), m_eval = __ballot(in && !(flags & SMPLX_F_INACTIVE));
-                // two new coordinates whose probing ended at the same empty slot (rare): the later one probes again below
-                bool clash = false;
-                {
-                    unsigned long long rest = m_new;
-                    while (rest) {
-                        const int j = __ffsll((long long)rest) - 1;
-                        rest &= rest - 1;
-                        const unsigned int fj = wave_rlu(pr.free_slot, j);
-                        if (j < lane && is_new && fj == pr.free_slot) clash = true;
-                    }
-                }
                 if (is_new) {
                     id = R.nstates + __popcll(m_new & below);
                     if (!clash) table_store_own(table, pr.free_slot, (const LDS_AS int*)X.coord[lane], nv, id);
@@ -713,6 +777,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     cost = sc.cost_prim & 0xFFFFFF;
                     ss = sstate_load(&P->st[sid]);
                 }
+                ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, cnt);
                 __syncthreads();                                     // B
                 SK_TICK(2);
             }
@@ -720,7 +785,6 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             // ---- which successors name the same state (two goal successors; a primitive that lands in an earlier one's
             // cell): the earliest lane keeps the state, the others refer to it ----
             const unsigned long long m_succ = __ballot(valid);
-            bool ac_complete = true;     // the ancestor cache holds every HBM-resident ancestor the pushes will read
             int alias = -1;
             {
                 unsigned long long rest = m_succ;
@@ -730,34 +794,6 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     const int sj = wave_rl(sid, j);
                     if (valid && j < lane && alias < 0 && sj == sid) alias = j;
                 }
-            }
-            // ---- ancestors of the slots n + 1 .. n + cnt (where this relaxation's pushes go) that lie beyond the LDS part of
-            // the heap: one round trip, all lanes ----
-            {
-                const int n = R.heap_size;
-                int nlev = 0, total = 0;
-                int my_idx[2] = {-1, -1};
-                ac_complete = true;
-                for (int j = 1; j <= SMPLX_AC_LEVELS; ++j) {
-                    int lo = (n + 1) >> j, hi = (n + cnt) >> j;
-                    if (hi > n) hi = n;
-                    if (hi < H.lh || cnt == 0) break;
-                    if (lo < H.lh) lo = H.lh;
-                    const int len = hi - lo + 1;
-                    if (total + len > SMPLX_AC_SLOTS || j == SMPLX_AC_LEVELS) { ac_complete = false; break; }
-                    if (lane == 0) { W.ac_lo[j] = lo; W.ac_hi[j] = hi; W.ac_base[j] = total; }
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const int e = lane + 64 * r - total;
-                        if (e >= 0 && e < len) my_idx[r] = lo + e;
-                    }
-                    total += len;
-                    nlev = j;
-                }
-                if (lane == 0) W.ac_nlev = nlev;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    if (my_idx[r] >= 0) W.ac_val[lane + 64 * r] = H.hbm[my_idx[r]];
             }
             // what earlier lanes of this wave stored (heap entries moved by the pop, the popped state's closing, new states'
             // rows) and others read below (a self-loop successor, the ancestor cache) has landed
