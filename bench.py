@@ -70,12 +70,15 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_shard leg (the box's CPU share)")
-    ap.add_argument("--planner-expansions", type=int, default=40000)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the cpu_shard leg; 0 = two runs, at nproc // 8 (a GPU's share of an 8-GPU node) and at nproc")
+    ap.add_argument("--planner-expansions", type=int, default=1000000,
+                    help="expansion bound of the single-query leg (the cfg-2 query reaches its goal after 194 806 expansions)")
     ap.add_argument("--queries-per-gpu", type=int, default=128, help="config-4 shard size per rank")
     ap.add_argument("--shard-expansions", type=int, default=20000, help="expansion bound per query in the shard leg")
     ap.add_argument("--host-threads", type=int, default=14,
-                    help="worker threads of smplx_plan_multi in the shard leg (searches and commits; one more thread submits to the GPU)")
+                    help="worker threads of the HOST-DRIVEN shard leg (searches and commits; one more thread submits to the GPU); "
+                         "the device-resident search needs one host thread")
     ap.add_argument("--overlap-streams", type=int, default=4, help="independent batches in flight for the secondary figure")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="timed steps whose kernels are bracketed by HIP events (default: steps/8, at least 1); every "
@@ -433,31 +436,88 @@ def main():
         del o
 
     if single and not args.no_planner:
-        # ---- one query through the plugin API: smplx_plan (hints from the engine's own OPEN) ------------------------
+        # ---- one query through the plugin API, run to its stated end: cfg 2's eps 5 ARA* until the goal is reached (first
+        # solution; smpl_test/src/call_planner.cpp:1727-1729).  A lone query takes the host-driven loop (smplx_plan) ----
         nb = args.planner_expansions
         sp2 = new_space()
         sp2.set_goal_joint(q_goal, cfg.goal_tol)
         sp2.set_start(q_start)
-        rg = sp2.plan(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+        rg = sp2.plan(p.eps0, p.eps_final, p.eps_delta, False, True, nb, nb)
         out["planner"] = {
-            "query": "cfg2 single query, ARA* eps 5->1 step 1, expansion bound %d, smplx_plan" % nb,
+            "query": "cfg2 single query, ARA* eps 5 until the first solution (improve off), expansion bound %d, smplx_plan "
+                     "(host-driven loop: sequential ARA* on the host, speculative frontier batches on the GPU)" % nb,
             "gpu_states_expanded_per_s": round(rg["expansions"] / rg["seconds"], 1),
             "succ_evals_per_s_committed": round(rg["committed_succ_evals"] / rg["seconds"], 1),
             "succ_evals_per_s_gpu_total": round(rg["gpu_succ_evals"] / rg["seconds"], 1),
-            "expansions": rg["expansions"], "path_cost": rg["cost"], "satisfied_eps": rg["satisfied_eps"],
+            "solved": rg["solved"], "expansions": rg["expansions"], "path_cost": rg["cost"], "path_len": int(len(rg["path"])),
+            "satisfied_eps": rg["satisfied_eps"], "states": sp2.num_states(),
             "gpu_seconds": round(rg["seconds"], 4),
             "gpu_succ_evals_total": rg["gpu_succ_evals"], "committed_succ_evals": rg["committed_succ_evals"],
             "gpu_batches": rg["gpu_batches"], "cache_hits": rg["cache_hits"], "cache_misses": rg["cache_misses"]}
+        # a second timed frontier, deep in that search: the LAST B states it created (next to the obstacles the search has been
+        # working around), so that joint limits, colliding edges and the sparse case of the compaction are inside a timed step
+        nst = sp2.num_states()
+        if nst > 2 * B:
+            Qd = np.stack([sp2.get_state(i)[0] for i in range(nst - B, nst)])
+            d_qd = torch.from_numpy(Qd).to(dev)
+            cnt_d = torch.zeros_like(d_cnt)
+
+            def step_deep():
+                space.expand_batch_k5_device(d_qd.data_ptr(), B, d_flags.data_ptr(), d_coord.data_ptr(), d_sq.data_ptr(),
+                                             d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_id.data_ptr(), d_reca.data_ptr(), cap_k5,
+                                             d_recb.data_ptr(), cap_k5, d_btab.data_ptr(), d_tot.data_ptr(), d_work.data_ptr(),
+                                             cnt_d.data_ptr(), stream.cuda_stream)
+            for _ in range(5):
+                step_deep()
+            torch.cuda.synchronize()
+            cnt_d.zero_()
+            nd = max(args.steps, 200)
+            td0 = time.perf_counter()
+            for _ in range(nd):
+                step_deep()
+            torch.cuda.synchronize()
+            td1 = time.perf_counter()
+            ev_d, va_d, lkr_d, lkd_d, cf_d, sl_d = space.counters_read(cnt_d.data_ptr(), B)
+            fl = d_flags.cpu().numpy()
+            out["deep_frontier"] = {
+                "states": f"the last {B} of the {nst} states the solved cfg-2 search created", "steps": nd,
+                "ms_per_step": round(1e3 * (td1 - td0) / nd, 4), "successor_evaluations_per_s": round(ev_d / (td1 - td0), 1),
+                "valid_fraction": round(va_d / max(ev_d, 1), 4),
+                "edges_out_of_limits": int(((fl & 0x20) != 0).sum()), "edges_in_collision": int(((fl & 0x40) != 0).sum()),
+                "edges_inactive": int(((fl & 0x10) != 0).sum()), "configs_per_launch": int(cf_d / nd)}
+            del d_qd, cnt_d
+        # the same query, 40 000 expansions, on the device-resident search (one workgroup: what one query of a shard gets)
+        rd_log = {}
+        os.environ["SMPLX_SEARCH"] = "device"
+        try:
+            sp3 = new_space()
+            sp3.set_goal_joint(q_goal, cfg.goal_tol)
+            sp3.set_start(q_start)
+            rd = sp3.plan(p.eps0, p.eps_final, p.eps_delta, True, True, 40000, 40000)
+            rd_log["expansion_log"] = rd["expansion_log"]
+            sc3 = sp3.search_counters()
+            tsum = sum(v for k_, v in sc3.items() if k_.startswith("t_")) or 1
+            out["planner_device"] = {
+                "query": "the cfg2 query, 40 000 expansions, device-resident ARA* (SMPLX_SEARCH=device): one persistent workgroup",
+                "states_expanded_per_s": round(rd["expansions"] / rd["seconds"], 1), "expansions": rd["expansions"],
+                "kernel_launches": rd["gpu_batches"], "seconds": round(rd["seconds"], 4),
+                "workgroup_time_share": {k_[2:]: round(v / tsum, 3) for k_, v in sc3.items() if k_.startswith("t_") and v},
+                "us_per_expansion": round(1e6 * rd["seconds"] / max(rd["expansions"], 1), 2)}
+            del sp3
+        except capi.SmplxError as e:
+            out["planner_device"] = {"error": str(e)[:200]}
+        finally:
+            os.environ.pop("SMPLX_SEARCH", None)
         if Oracle is not None:
             o2 = Oracle(cfg)
             o2.set_goal_joint(q_goal, cfg.goal_tol)
             o2.set_start(q_start)
-            o2.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+            o2.search_params(p.eps0, p.eps_final, p.eps_delta, False, True, nb, nb)
             ro = o2.plan()
             out["planner"].update({
                 "cpu_states_expanded_per_s": round(ro["expansions"] / ro["seconds"], 1), "cpu_seconds": round(ro["seconds"], 4),
                 "cpu_succ_evals_per_s": round(ro["succ_evals"] / ro["seconds"], 1),
-                "parity": {"cost_equal": bool(ro["cost"] == rg["cost"]),
+                "parity": {"cost_equal": bool(ro["cost"] == rg["cost"]), "solved_equal": bool(ro["ok"] == rg["solved"]),
                            "expansions_equal": bool(ro["expansions"] == rg["expansions"]),
                            "expanded_ids_equal": bool(np.array_equal(ro["expansion_log"], rg["expansion_log"])),
                            "path_equal": bool(np.array_equal(ro["path"], rg["path"])),
@@ -490,7 +550,8 @@ def main():
                 exe = build_driver("sbpl_loop_driver", td)
                 c2 = copy.copy(cfg)
                 c2.start, c2.goal = list(q_start), list(q_goal)
-                write_query(c2, td, [p.eps0, p.eps_final, p.eps_delta, nb, nb])
+                nbp = 40000
+                write_query(c2, td, [p.eps0, p.eps_final, p.eps_delta, nbp, nbp])
                 pr = subprocess.run([exe, td, "log"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                 lines = {l.split(" ", 1)[0]: l.split(" ", 1)[1] if " " in l else "" for l in pr.stdout.decode().splitlines()}
                 if pr.returncode == 0 and "result" in lines:
@@ -501,25 +562,29 @@ def main():
                                   "GetSuccs / GetGoalHeuristic, no smplx_hint_frontier",
                         "states_expanded_per_s": round(int(nexp) / float(secs), 1), "expansions": int(nexp),
                         "path_cost": int(cost), "seconds": round(float(secs), 4), **{k: int(v) for k, v in st.items()},
-                        "log_equals_smplx_plan": bool(np.array_equal(np.array(lines.get("log", "").split(), dtype=np.int64),
-                                                                     rg["expansion_log"]))}
+                        "log_equals_device_search": bool("expansion_log" in rd_log and
+                                                         np.array_equal(np.array(lines.get("log", "").split(), dtype=np.int64), rd_log["expansion_log"]))}
                 else:
                     out["planner_plain"] = {"error": pr.stderr.decode()[-300:]}
         except Exception as e:   # the secondary leg must not take the bench line down
             out["planner_plain"] = {"error": repr(e)[:300]}
 
     if not args.no_shard and not args.no_planner:
-        # ---- BASELINE config 4: this rank's 128 queries through smplx_plan_multi -------------------------------------
+        # ---- BASELINE config 4: this rank's 128 queries through smplx_plan_multi: the device-resident search, one persistent
+        # workgroup per query, all in one launch ------------------------------------------------------------------------
         nb = args.shard_expansions
-        spaces = []
-        t_set = time.perf_counter()
-        for a, b in zip(S_mine, G_mine):
-            sp = new_space(1024)
-            sp.set_goal_joint(b, cfg.goal_tol)     # BFS_3D::run for this goal, to completion
-            sp.set_start(a)
-            spaces.append(sp)
-        torch.cuda.synchronize()
-        t_set = time.perf_counter() - t_set
+
+        def make_spaces():
+            t_ = time.perf_counter()
+            sps = []
+            for a_, b_ in zip(S_mine, G_mine):
+                sp = new_space(1024)
+                sp.set_goal_joint(b_, cfg.goal_tol)     # BFS_3D::run for this goal, to completion
+                sp.set_start(a_)
+                sps.append(sp)
+            torch.cuda.synchronize()
+            return sps, time.perf_counter() - t_
+        spaces, t_set = make_spaces()
         if dist is not None:
             dist.barrier()
         res, wall = ([], 0.0)
@@ -533,79 +598,92 @@ def main():
         tot_exp = sum(r["expansions"] for r in res)
         tot_commit = sum(r["committed_succ_evals"] for r in res)
         tot_gpu = sum(r["gpu_succ_evals"] for r in res)
-        sc2 = shard.gather_scalars([tot_exp, wall, tot_commit, tot_gpu, sum(r["gpu_batches"] for r in res), t_set], dist, world, coll_dev)
+        sc2 = shard.gather_scalars([tot_exp, wall, tot_commit, tot_gpu, max([r["gpu_batches"] for r in res] or [0]), t_set], dist, world, coll_dev)
         tmax2 = float(sc2[:, 1].max())
+        tset2 = float(sc2[:, 5].max())
         summ = shard.summarize(rows)
+        on_device = bool(res) and all(r["cache_misses"] == 0 for r in res)
         out["shard"] = {
             "workload": f"cfg 4: queries [{first}, {last}) of the seeded list (seed 4) per rank, {args.queries_per_gpu} per GPU, "
-                        f"ARA* eps 5->1, expansion bound {nb} per query, smplx_plan_multi, {args.host_threads} worker threads + 1 GPU submitter",
+                        f"ARA* eps 5->1, expansion bound {nb} per query, smplx_plan_multi",
+            "search": "device-resident: one persistent workgroup per query, one launch for the shard, no host round trips"
+                      if on_device else f"host-driven loop, {args.host_threads} worker threads + 1 GPU submitter",
             "queries": summ["queries"], "solved": summ["solved"], "wall_seconds_max": round(tmax2, 4),
             "states_expanded_per_s": round(float(sc2[:, 0].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
             "succ_evals_per_s_committed": round(float(sc2[:, 2].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
             "succ_evals_per_s_gpu_total": round(float(sc2[:, 3].sum()) / tmax2, 1) if tmax2 > 0 else 0.0,
-            "expansions_total": summ["expansions_total"], "gpu_batches": int(sc2[:, 4].sum()),
-            "setup_seconds_max": round(float(sc2[:, 5].max()), 3), "cost_checksum": summ["cost_checksum"],
-            "setup_is": "goal + BFS_3D::run + start for every query of the rank, before the timed region"}
+            "expansions_total": summ["expansions_total"], "kernel_launches_or_batches": int(sc2[:, 4].max()),
+            "setup_seconds_max": round(tset2, 3), "cost_checksum": summ["cost_checksum"],
+            "setup_is": "goal + BFS_3D::run + start for every query of the rank (the GPU's BFS per goal), outside wall_seconds",
+            "states_expanded_per_s_incl_setup": round(float(sc2[:, 0].sum()) / (tmax2 + tset2), 1) if tmax2 > 0 else 0.0}
+        if single and spaces and on_device:
+            sc0 = spaces[0].search_counters()
+            tsum = sum(v for k_, v in sc0.items() if k_.startswith("t_")) or 1
+            out["shard"]["workgroup_time_share_query0"] = {k_[2:]: round(v / tsum, 3) for k_, v in sc0.items() if k_.startswith("t_") and v}
+            out["shard"]["us_per_expansion_query0"] = round(tsum * 0.01 / max(res[0]["expansions"], 1), 2)   # ticks of 10 ns
+            # the same shard on the host-driven loop (what round 2 measured): secondary, A/B on the same box
+            os.environ["SMPLX_SEARCH"] = "host"
+            try:
+                sp_h, _ = make_spaces()
+                res_h, wall_h = capi.Space.plan_multi(sp_h, p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb, host_threads=args.host_threads)
+                out["shard_host_loop"] = {
+                    "search": f"host-driven loop, {args.host_threads} worker threads + 1 GPU submitter (SMPLX_SEARCH=host)",
+                    "states_expanded_per_s": round(sum(r["expansions"] for r in res_h) / wall_h, 1), "wall_seconds": round(wall_h, 4),
+                    "gpu_batches": int(sum(r["gpu_batches"] for r in res_h)),
+                    "identical_to_device_search": bool(all(a_["cost"] == b_["cost"] and a_["expansions"] == b_["expansions"] and
+                                                           np.array_equal(a_["path"], b_["path"]) for a_, b_ in zip(res, res_h)))}
+                del sp_h
+            finally:
+                os.environ.pop("SMPLX_SEARCH", None)
         if single and Oracle is not None and spaces:
             # the same queries on the oracle, one per host thread ("nproc independent queries in parallel,
-            # one per core"); a bounded sample: every thread takes queries t, t+T, ... until the budget is spent
-            T = host_threads_available(args.cpu_threads)
-            budget = args.cpu_seconds
-            acc = [dict(exp=0, ev=0, plan_s=0.0, setup_s=0.0, n=0, same=True) for _ in range(T)]
-            t_all = time.perf_counter()
+            # one per core"); a bounded sample: every thread takes queries t, t+T, ... until the budget is spent.
+            # Twice: with a GPU's share of the cores of an 8-GPU node (nproc // 8), and with all of them.
+            def cpu_shard_run(T, budget):
+                acc = [dict(exp=0, ev=0, plan_s=0.0, setup_s=0.0, n=0, same=True) for _ in range(T)]
+                t_all = time.perf_counter()
 
-            def worker(t):
-                k = t
-                while k < len(spaces) and time.perf_counter() - t_all < budget:
-                    ts = time.perf_counter()
-                    o = Oracle(cfg)               # a fresh context per query: ids restart at the goal (0) and the start (1)
-                    o.set_goal_joint(G_mine[k], cfg.goal_tol)
-                    o.set_start(S_mine[k])
-                    acc[t]["setup_s"] += time.perf_counter() - ts
-                    o.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
-                    r = o.plan()
-                    acc[t]["exp"] += r["expansions"]; acc[t]["ev"] += r["succ_evals"]; acc[t]["plan_s"] += r["seconds"]
-                    acc[t]["n"] += 1
-                    acc[t]["same"] &= bool(r["cost"] == res[k]["cost"] and r["expansions"] == res[k]["expansions"] and
-                                           np.array_equal(r["expansion_log"], res[k]["expansion_log"]))
-                    k += T
-            th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            busy = max(a["plan_s"] for a in acc) or 1.0
-            nq_cpu = sum(a["n"] for a in acc)
-            out["cpu_shard"] = {
-                "value": round(sum(a["exp"] for a in acc) / busy, 1), "unit": "states expanded/s", "cores": T, "kind": "port",
-                "succ_evals_per_s": round(sum(a["ev"] for a in acc) / busy, 1),
-                "sample": f"{nq_cpu} of the {len(spaces)} shard queries, one per host thread at a time ({T} threads, oracle/ "
-                          f"C++ -O2, same expansion bound), rate = expansions of all threads / longest thread's time inside "
-                          f"plan(); BFS per goal ({sum(a['setup_s'] for a in acc) / max(nq_cpu, 1):.2f} s each on the CPU) excluded on both sides",
-                "all_sampled_queries_identical_to_gpu": bool(all(a["same"] for a in acc)), "host_cores": os.cpu_count()}
-        if single and Oracle is not None and spaces:
-            # row N3: postProcessPath (interpolate -> shortcut -> interpolate) of a found path -- the config-2 query itself
-            # does not reach its goal within the planner leg's bound under the fork's semantics, so the first shard query
-            # that solved is taken; upstream limit test so that the interpolation passes do their work
-            k = next((i for i, r in enumerate(res) if r["solved"]), None)
-            if k is not None:
-                sp = spaces[k]
-                P = sp.extract_path(res[k]["path"])
-                sp.post_process_path(P, True, True, True)
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    got, st = sp.post_process_path(P, True, True, True)
-                tg = (time.perf_counter() - t0) / 5
-                o3 = Oracle(cfg)
-                t0 = time.perf_counter()
-                want, ec, sc_ = o3.post_process(P, True, True, True)
-                tc = time.perf_counter() - t0
-                out["post_process"] = {
-                    "query": int(first + k), "points_in": int(len(P)), "points_out": int(len(got)), "gpu_ms": round(tg * 1e3, 3),
-                    "cpu_ms": round(tc * 1e3, 3), "gpu_configs_checked": int(st["configs"]), "gpu_batches": int(st["edge_batches"]),
-                    "cpu_edge_checks": int(ec), "cpu_state_checks": int(sc_),
-                    "equal": bool(got.shape == want.shape and np.array_equal(got, want))}
-                del o3
+                def worker(t):
+                    k = t
+                    while k < len(spaces) and time.perf_counter() - t_all < budget:
+                        ts = time.perf_counter()
+                        o = Oracle(cfg)               # a fresh context per query: ids restart at the goal (0) and the start (1)
+                        o.set_goal_joint(G_mine[k], cfg.goal_tol)
+                        o.set_start(S_mine[k])
+                        acc[t]["setup_s"] += time.perf_counter() - ts
+                        o.search_params(p.eps0, p.eps_final, p.eps_delta, True, True, nb, nb)
+                        r = o.plan()
+                        acc[t]["exp"] += r["expansions"]; acc[t]["ev"] += r["succ_evals"]; acc[t]["plan_s"] += r["seconds"]
+                        acc[t]["n"] += 1
+                        acc[t]["same"] &= bool(r["cost"] == res[k]["cost"] and r["expansions"] == res[k]["expansions"] and
+                                               np.array_equal(r["expansion_log"], res[k]["expansion_log"]))
+                        k += T
+                th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                busy = max(a_["plan_s"] for a_ in acc) or 1.0
+                busy_all = max(a_["plan_s"] + a_["setup_s"] for a_ in acc) or 1.0
+                nq_cpu = sum(a_["n"] for a_ in acc)
+                return {
+                    "value": round(sum(a_["exp"] for a_ in acc) / busy, 1), "unit": "states expanded/s", "cores": T, "kind": "port",
+                    "succ_evals_per_s": round(sum(a_["ev"] for a_ in acc) / busy, 1),
+                    "states_expanded_per_s_incl_setup": round(sum(a_["exp"] for a_ in acc) / busy_all, 1),
+                    "bfs_and_start_seconds_per_query": round(sum(a_["setup_s"] for a_ in acc) / max(nq_cpu, 1), 3),
+                    "sample": f"{nq_cpu} of the {len(spaces)} shard queries, one per host thread at a time ({T} threads, oracle/ "
+                              f"C++ -O2, same expansion bound), rate = expansions of all threads / longest thread's time inside "
+                              f"plan(); the _incl_setup figure adds BFS_3D::run + setStart per query on both sides",
+                    "all_sampled_queries_identical_to_gpu": bool(all(a_["same"] for a_ in acc)), "host_cores": os.cpu_count()}
+            ncpu = host_threads_available(1 << 20)
+            if args.cpu_threads > 0:
+                out["cpu_shard"] = cpu_shard_run(host_threads_available(args.cpu_threads), args.cpu_seconds)
+            else:
+                out["cpu_shard"] = cpu_shard_run(max(1, ncpu // 8), args.cpu_seconds)
+                out["cpu_shard"]["cores_are"] = "nproc // 8: one GPU's share of the host cores of an 8-GPU node"
+                if ncpu // 8 != ncpu:
+                    out["cpu_shard_all_cores"] = cpu_shard_run(ncpu, args.cpu_seconds)
+                    out["cpu_shard_all_cores"]["cores_are"] = "nproc: every host core of the box (SURVEY 8d)"
         del spaces
 
     if rank == 0:

@@ -143,13 +143,18 @@ def test_config4_shard_128_queries_on_one_gpu(cfg2):
     assert sum(m["expansions"] for m in multi) > 100 * nb
 
 
-def test_config5_dual_arm_512cube():
+@pytest.fixture(scope="module")
+def cfg5():
+    return scenes.config5()
+
+
+def test_config5_dual_arm_512cube(cfg5):
     """cfg 5 at full size: 14-DOF dual arm, 512^3 grid @ 0.01 m, 59 primitives, 85 checked link pairs: BFS grid,
     a 64-state expansion batch and a bounded eps 10 -> 1 search, all identical to the oracle."""
     from oracle_binding import Oracle
     from smpl_amd import capi
     _need_gpu()
-    cfg = scenes.config5()
+    cfg = cfg5
     assert cfg.grid.dims == (512, 512, 512) and cfg.grid.res == 0.01
     # row N1 at this size: the field built on the GPU from the box list equals the host builder's
     gr = cfg.grid
@@ -170,6 +175,121 @@ def test_config5_dual_arm_512cube():
     o.set_order(chain=False)
     assert o.set_start(cfg.start) == s.set_start(cfg.start)
     _same_search(o, s, cfg.params.eps0, 3000, 3000)
+
+
+def test_config5_epsilon_decreasing_search_with_table_growth(cfg5, monkeypatch):
+    """cfg 5 to its stated end as far as a test can afford ("eps-decreasing ARA* ... stress hash-table occupancy"):
+    eps 10 -> 1 in steps of 1 with 20 000 expansions -- a solution at eps 10, then SEVEN epsilon steps (INCONS -> OPEN, reorder,
+    re-expansions), 315 000 states in 64-byte table slots.  Twice on the GPU, both equal to the oracle: the host-driven loop
+    with the device copy of the state table (2^18 slots, grown once past 131 072 states), and the device-resident search with
+    a small first capacity (arena and table grown several times, the 512-thread block with the heap's LDS part at its smallest)."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = cfg5
+    o = Oracle(cfg)
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    o.set_start(cfg.start)
+    o.search_params(cfg.params.eps0, 1.0, 1.0, True, True, 20000, 20000)
+    eo = o.plan()
+    assert eo["ok"] == 1 and eo["cost"] > 0 and eo["eps"] <= cfg.params.eps0 - 2.0 and o.num_states() > (1 << 17)
+    for mode in ("host", "device"):
+        monkeypatch.setenv("SMPLX_SEARCH", mode)
+        monkeypatch.setenv("SMPLX_DEVICE_TABLE", "1")
+        s = capi.Space.from_config(cfg, batch_states=4096)
+        if mode == "device":
+            if not s.specialized()[0]:
+                pytest.skip("generic kernels: the search kernel's block does not fit this robot's LDS scratch without the per-robot build")
+            s.set_search_capacity(40000)
+        s.set_goal_joint(cfg.goal, cfg.goal_tol)
+        assert s.set_start(cfg.start) == 1
+        go = s.plan(cfg.params.eps0, 1.0, 1.0, True, True, 20000, 20000)
+        assert go["solved"] == 1 and go["cost"] == eo["cost"] and go["satisfied_eps"] == eo["eps"], mode
+        assert go["expansions"] == eo["expansions"] and np.array_equal(go["expansion_log"], eo["expansion_log"]), mode
+        assert np.array_equal(go["path"], eo["path"]) and s.num_states() == o.num_states(), mode
+        assert go["committed_succ_evals"] == eo["succ_evals"], mode
+        if mode == "device":
+            sc = s.search_counters()
+            assert sc["grows"] >= 3 and go["cache_misses"] == 0, sc
+        del s
+
+
+@pytest.fixture(scope="module")
+def cfg2_solution(cfg2):
+    """The oracle's cfg-2 search run to its first solution (eps 5, improve off): 194 806 expansions, ~17 s on one core."""
+    from oracle_binding import Oracle
+    o = Oracle(cfg2)
+    o.set_goal_joint(cfg2.goal, cfg2.goal_tol)
+    o.set_start(cfg2.start)
+    o.search_params(cfg2.params.eps0, 1.0, 1.0, False, True, 1000000, 1000000)
+    r = o.plan()
+    r["num_states"] = o.num_states()
+    return r
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_config2_eps5_search_reaches_its_goal(cfg2, cfg2_solution, mode, monkeypatch):
+    """cfg 2 to its stated end ("eps = 5 ARA*", smpl_test/src/call_planner.cpp:1727-1729): the search runs until it reaches the
+    goal -- 194 806 expansions, 1.09 M states -- and returns the oracle's path, cost and expansion log; once through the
+    host-driven loop (what smplx_plan does for a lone query), once device-resident."""
+    from smpl_amd import capi
+    _need_gpu()
+    cfg, eo = cfg2, cfg2_solution
+    assert eo["ok"] == 1 and eo["cost"] > 0 and eo["expansions"] > 100000
+    monkeypatch.setenv("SMPLX_SEARCH", mode)
+    s = capi.Space.from_config(cfg, batch_states=4096)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    assert s.set_start(cfg.start) == 1
+    go = s.plan(cfg.params.eps0, 1.0, 1.0, False, True, 1000000, 1000000, cap=4096)
+    assert go["solved"] == 1 and go["cost"] == eo["cost"] > 0 and go["satisfied_eps"] == eo["eps"] == 5.0
+    assert go["expansions"] == eo["expansions"] and np.array_equal(go["expansion_log"], eo["expansion_log"])
+    assert np.array_equal(go["path"], eo["path"]) and s.num_states() == eo["num_states"]
+    assert go["committed_succ_evals"] == eo["succ_evals"]
+    q = s.extract_path(go["path"])
+    assert q.shape == (len(eo["path"]), 7) and np.array_equal(q[0], np.array(cfg.start))
+
+
+def test_config4_shard_of_the_last_rank(cfg2, monkeypatch):
+    """The cfg-4 shard of a non-zero rank: queries [896, 1024) of the seeded list (rank 7 of 8), one workgroup each in one
+    launch of the device-resident search; every query equals the host-driven loop's result, a sample of 8 the oracle's."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    _need_gpu()
+    cfg = cfg2
+    grid = capi.Grid(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, cfg.grid.d2)
+    model = capi.Model(cfg.robot_text)
+    probe = capi.Space(model, grid, cfg.mprim, cfg.params, 256)
+    cs, cg = scenes.config4_candidates()
+    S, G = scenes.config4_queries(cs, cg, probe.state_valid_batch(cs)[0], probe.state_valid_batch(cg)[0])
+    first, last = scenes.shard_range(7, 8)
+    assert (first, last) == (896, 1024)
+    S, G = S[first:last], G[first:last]
+    nb = 2500
+
+    def make():
+        out = []
+        for a, b in zip(S, G):
+            sp = capi.Space(model, grid, cfg.mprim, cfg.params, 1024)
+            sp.set_goal_joint(b, cfg.goal_tol)
+            sp.set_start(a)
+            out.append(sp)
+        return out
+    dev, wall = capi.Space.plan_multi(make(), 5.0, 1.0, 1.0, True, True, nb, nb)
+    assert all(r["cache_misses"] == 0 for r in dev)               # the device-resident search ran
+    monkeypatch.setenv("SMPLX_SEARCH", "host")
+    host, _ = capi.Space.plan_multi(make(), 5.0, 1.0, 1.0, True, True, nb, nb, host_threads=8)
+    for i, (a, b) in enumerate(zip(dev, host)):
+        assert a["solved"] == b["solved"] and a["cost"] == b["cost"] and a["expansions"] == b["expansions"], i
+        assert np.array_equal(a["expansion_log"], b["expansion_log"]) and np.array_equal(a["path"], b["path"]), i
+    for i in range(0, 128, 16):
+        o = Oracle(cfg)
+        o.set_goal_joint(G[i], cfg.goal_tol)
+        o.set_start(S[i])
+        o.search_params(5.0, 1.0, 1.0, True, True, nb, nb)
+        e = o.plan()
+        m = dev[i]
+        assert e["ok"] == m["solved"] and e["cost"] == m["cost"] and np.array_equal(e["expansion_log"], m["expansion_log"]), i
+    assert sum(m["solved"] for m in dev) > 0
 
 
 def test_strictly_growing_and_shrinking_batches_on_one_space(small_cfg):

@@ -204,11 +204,12 @@ def test_device_and_host_searches_share_one_lattice(small_cfg, monkeypatch):
         assert (go["cache_misses"] == 0) == (mode == "device"), k
 
 
-def test_config2_bounded_search_on_the_device():
-    """BASELINE cfg 2 (256^3, eps 5): the bounded search of the bench's planner leg, device-resident, against the oracle."""
+def test_config2_bounded_search_on_the_device(monkeypatch):
+    """BASELINE cfg 2 (256^3, eps 5): a bounded search, device-resident, against the oracle."""
     from oracle_binding import Oracle
     from smpl_amd import capi
     _need_gpu()
+    monkeypatch.setenv("SMPLX_SEARCH", "device")
     cfg = scenes.config2()
     o = Oracle(cfg)
     s = capi.Space.from_config(cfg, batch_states=4096)
