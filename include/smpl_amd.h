@@ -60,14 +60,34 @@ void smplx_grid_destroy(smplx_grid* g);
  * (the one-cell layer around the grid is occupied): d2 = min(dmax^2, min over occupied/border cells of |c - o|^2).
  * The reference's own bucketed propagation (distance_map.hpp:627-839) depends on its pop order where distances tie and
  * cannot be compiled here (Eigen): parity with it is unpinned; exactness is tested against brute force.
- * Every change recomputes the whole field (three separable passes: milliseconds at 256^3). */
+ * A new field takes three separable passes over the grid; an edit re-runs them on the window its cells can reach. */
 int smplx_grid_create_empty(const double origin[3], int nx, int ny, int nz, double res, double max_dist, smplx_grid** out);
+/* OccupancyGrid's ref_counted mode (smpl/include/smpl/occupancy_grid.h:66-74, initRefCounts occupancy_grid.cpp:424-441):
+ * every cell keeps the number of times it was added; a cell becomes an obstacle when its count leaves 0 and free again
+ * when it returns to 0 (a point listed twice counts twice; removing from a cell with count 0 does nothing).  Turning it
+ * on gives every occupied cell the count 1. */
+int smplx_grid_set_ref_counted(smplx_grid* g, int on);
 /* boxes: n x {cx, cy, cz, sx, sy, sz} (world metres), the objects of a scene file (smpl_test/src/call_planner.cpp:158-207):
  * a box occupies the cells from the cell of its low corner to the cell of its high corner */
 int smplx_grid_add_boxes(smplx_grid* g, const double* boxes, int n);
 /* xyz: n world points (voxel centres); points outside the grid are skipped (distance_map.hpp:312-316) */
 int smplx_grid_add_points(smplx_grid* g, const double* xyz, int n);
 int smplx_grid_remove_points(smplx_grid* g, const double* xyz, int n);
+/* OccupancyGrid::updatePointsInField -> DistanceMap::updatePointsInMap (occupancy_grid.cpp:408-415, distance_map.hpp:367-435):
+ * as sets of cells, the obstacles in old \ new are removed and those in new \ old added; like the reference's it does not
+ * touch the reference counts */
+int smplx_grid_update_points(smplx_grid* g, const double* old_xyz, int n_old, const double* new_xyz, int n_new);
+/* the reference counts, x-major / z fastest like d2 (SMPLX_E_STATE when the grid keeps none) */
+int smplx_grid_copy_counts(const smplx_grid* g, int32_t* counts);
+/* cells the last edit recomputed: the bounding box of the changed cells grown by ceil(max_dist / res) along every axis (an
+ * edit is incremental, like the reference's propagation), or the whole grid when that box covers more than half of it */
+long long smplx_grid_last_edit_cells(const smplx_grid* g);
+/* EDITS AND SPACES.  CollisionChecker queries (smplx_cc_*, smplx_expand_batch) read the field as it is.  A planning space,
+ * however, caches successor lists (the reference's ManipLattice re-evaluates every GetSuccs), and its BFS walls are those of
+ * the field it was created on (BfsHeuristic::syncGridAndBfs runs once, at init: bfs_heuristic.cpp:52-71, 331-353 -- the
+ * reference's heuristic has the same staleness).  After an edit, smplx_get_succs / smplx_plan* on a space of that grid
+ * return SMPLX_E_STATE until the goal is set again (which restarts the lattice); re-create the space to get new walls.
+ * Coordinates must be finite with |x| < 1e6 (SMPLX_E_ARG). */
 /* the field as smplx_grid_create takes it: d2[nx*ny*nz], x-major, z fastest */
 int smplx_grid_copy_d2(const smplx_grid* g, int32_t* d2);
 

@@ -35,7 +35,7 @@ SYMBOLS = [
     "smplx_table_sync", "smplx_compact_rec_b_bytes", "smplx_compact_blocks", "smplx_expand_batch_k5_device", "smplx_expand_batch_k5",
     "smplx_compact_totals_len", "smplx_compact_capacity",
     "smplx_grid_create_empty", "smplx_grid_add_boxes", "smplx_grid_add_points", "smplx_grid_remove_points", "smplx_grid_copy_d2",
-    "smplx_search_counters",
+    "smplx_search_counters", "smplx_grid_set_ref_counted", "smplx_grid_update_points", "smplx_grid_copy_counts", "smplx_grid_last_edit_cells",
 ]
 
 
@@ -154,6 +154,26 @@ class Grid:
         p = _f64(xyz).reshape(-1, 3)
         lib().smplx_grid_remove_points.argtypes = [C.c_void_p, _dp, C.c_int]
         _chk(lib().smplx_grid_remove_points(self.h, _p(p, _dp), p.shape[0]))
+
+    def set_ref_counted(self, on=True):
+        lib().smplx_grid_set_ref_counted.argtypes = [C.c_void_p, C.c_int]
+        _chk(lib().smplx_grid_set_ref_counted(self.h, int(on)))
+
+    def update_points(self, old_xyz, new_xyz):
+        a = _f64(old_xyz).reshape(-1, 3); b = _f64(new_xyz).reshape(-1, 3)
+        lib().smplx_grid_update_points.argtypes = [C.c_void_p, _dp, C.c_int, _dp, C.c_int]
+        _chk(lib().smplx_grid_update_points(self.h, _p(a, _dp), a.shape[0], _p(b, _dp), b.shape[0]))
+
+    def counts(self):
+        out = np.zeros(self.dims, np.int32)
+        lib().smplx_grid_copy_counts.argtypes = [C.c_void_p, _ip]
+        _chk(lib().smplx_grid_copy_counts(self.h, _p(out, _ip)))
+        return out
+
+    def last_edit_cells(self):
+        lib().smplx_grid_last_edit_cells.restype = C.c_longlong
+        lib().smplx_grid_last_edit_cells.argtypes = [C.c_void_p]
+        return int(lib().smplx_grid_last_edit_cells(self.h))
 
     def d2(self):
         out = np.zeros(self.dims, np.int32)

@@ -229,6 +229,7 @@ struct smplx_space {
     int bfs_levels = 0;
     int wall_thr = -1;
     bool goal_set = false;
+    uint64_t grid_epoch = 0;         // the grid's edit count when the goal was set: the successor caches belong to that field
     double goal_xyz[3] = {0, 0, 0};
     double start_xyz[3] = {0, 0, 0};   // planning-link position of the start state (getMetricStartDistance)
     int status = SMPLX_OK;            // sticky: first error of a call that has no way to report one (smplx_space_status)
@@ -1131,6 +1132,7 @@ void smplx_grid_destroy(smplx_grid* g)
     if (g->d_d2) (void)hipFree(g->d_d2);
     if (g->d_occ) (void)hipFree(g->d_occ);
     if (g->d_tmp) (void)hipFree(g->d_tmp);
+    if (g->d_counts) (void)hipFree(g->d_counts);
     delete g;
 }
 
@@ -1515,6 +1517,7 @@ static int finish_goal(smplx_space* s)
     if (int e = upload_space(s)) return e;
     if (int e = run_bfs(s, s->goal_xyz)) return e;
     s->goal_set = true;
+    s->grid_epoch = s->grid->epoch;
     // a new goal starts a new query: the state table restarts (ids are per query)
     reset_lattice(s);
     // heuristic of the goal id = BFS cost at the goal pose's cell (manip_lattice.cpp:1176-1190)
@@ -1829,6 +1832,7 @@ int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int 
 {
     if (!s || !n) return set_error(SMPLX_E_ARG, "null argument");
     if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
+    if (s->grid->epoch != s->grid_epoch) return set_error(SMPLX_E_STATE, "the grid was edited after the goal was set: cached successors are stale, set the goal again");
     if (int e = pull_lattice(s)) return e;
     if (!s->plain_mode) {
         // first GetSuccs from outside: start mirroring the caller's g-values (the start has g = 0, arastar.cpp:172-176)
@@ -2621,6 +2625,7 @@ int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p,
         if (!s) return set_error(SMPLX_E_ARG, "null space");
         if (!s->goal_set) return set_error(SMPLX_E_STATE, "goal not set");
         if (s->start_id < 0) return set_error(SMPLX_E_STATE, "start not set");
+        if (s->grid->epoch != s->grid_epoch) return set_error(SMPLX_E_STATE, "the grid was edited after the goal was set: cached successors are stale, set the goal again");
         if (int e = pull_lattice(s)) return e;
         if (int e = pull_log(s)) return e;
         fill_search(S[q], s, p);

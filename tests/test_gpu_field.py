@@ -93,3 +93,132 @@ def test_reference_env_file_to_gpu_grid():
     cfg = scenes.config1()
     g = capi.Grid.from_boxes(cfg.grid.origin, cfg.grid.dims, cfg.grid.res, cfg.grid.max_dist, [(c, s) for (_, c, s) in objs])
     assert np.array_equal(g.d2(), cfg.grid.d2)
+
+
+def test_reference_counts_duplicate_adds_and_partial_removes():
+    """OccupancyGrid's ref_counted mode (occupancy_grid.cpp:357-406, 424-441) against a host model of its loops: points listed
+    twice count twice, a cell is an obstacle while its count is positive, removing from an empty cell does nothing; the
+    field after every step equals the brute-force transform of the cells with a positive count."""
+    from smpl_amd import capi
+    rng = np.random.default_rng(11)
+    dims, res, max_dist, origin = (14, 11, 9), 0.05, 0.25, (0.2, -0.1, 0.0)
+    dmax = int(np.ceil(max_dist * (1.0 / res)))
+    g = capi.Grid.empty(origin, dims, res, max_dist)
+    g.add_points(np.asarray(origin) + np.array([[3, 3, 3], [4, 3, 3]]) * res)      # obstacles from before the counts are switched on
+    g.set_ref_counted(True)
+    counts = np.zeros(dims, np.int64)
+    counts[3, 3, 3] = counts[4, 3, 3] = 1                                          # initRefCounts: 1 where occupied
+    assert np.array_equal(g.counts(), counts)
+
+    def pts(cells):
+        return np.asarray(origin) + np.asarray(cells) * res
+
+    for step in range(8):
+        cells = rng.integers(0, dims, size=(12, 3))
+        cells = np.vstack([cells, cells[:5], cells[:2], [[3, 3, 3]]])             # duplicates inside one call
+        outside = np.array([[40.0, 0.0, 0.0], [0.0, -7.0, 0.0]])
+        if step % 2 == 0:
+            g.add_points(np.vstack([pts(cells), outside]))
+            for c in cells:
+                counts[tuple(c)] += 1
+        else:
+            rem = np.vstack([cells[::2], rng.integers(0, dims, size=(6, 3))])     # partial removal + cells that were never added
+            g.remove_points(np.vstack([pts(rem), outside]))
+            for c in rem:
+                if counts[tuple(c)] > 0:
+                    counts[tuple(c)] -= 1
+        assert np.array_equal(g.counts(), counts), step
+        assert np.array_equal(g.d2(), _brute_force(counts > 0, dmax)), step
+    assert (counts > 1).any() and (counts == 0).any()
+
+
+def test_incremental_edit_equals_a_field_built_from_scratch():
+    """An edit recomputes only the window its cells can reach (their bounding box grown by dmax); after a series of adds,
+    removes and updatePointsInField the field equals one built from scratch from the same obstacles -- at 128^3 with a
+    cap of 20 cells, where the window of a point is 41^3 of 2 M cells."""
+    from smpl_amd import capi
+    rng = np.random.default_rng(3)
+    dims, res, max_dist, origin = (128, 128, 128), 0.02, 0.4, (-0.5, -0.5, 0.0)
+    boxes = [((0.3, 0.2, 0.6), (0.4, 0.6, 0.04)), ((-0.1, 0.9, 1.4), (0.2, 0.2, 0.3))]
+    g = capi.Grid.from_boxes(origin, dims, res, max_dist, boxes)
+    whole = 128 ** 3
+
+    def world(cells):
+        return np.asarray(origin) + np.asarray(cells, float) * res
+
+    # one point: a 41^3 window (clipped at the faces)
+    g.add_points(world([[64, 64, 64]]))
+    assert g.last_edit_cells() == 41 ** 3
+    g.add_points(world([[2, 120, 64]]))
+    assert g.last_edit_cells() == 23 * 28 * 41
+    added = [[64, 64, 64], [2, 120, 64]]
+    cloud_a = rng.integers(60, 90, size=(200, 3))                                 # (clear of the boxes: removing a point frees its cell)
+    cloud_b = np.vstack([cloud_a[:120], rng.integers(80, 110, size=(90, 3))])
+    g.add_points(world(cloud_a))
+    g.update_points(world(cloud_a), world(cloud_b))                               # old \\ new removed, new \\ old added
+    g.remove_points(world([[64, 64, 64]]))
+    added = [added[1]]
+    final_points = np.vstack([np.unique(cloud_b, axis=0), added])
+    fresh = capi.Grid.from_boxes(origin, dims, res, max_dist, boxes)
+    fresh.add_points(world(final_points))
+    assert fresh.last_edit_cells() <= whole
+    assert np.array_equal(g.d2(), fresh.d2())
+    # and both equal the host builder's transform (scipy EDT, smpl_amd/scenes.py build_grid) of boxes + points-as-boxes
+    host = scenes.build_grid(origin, dims, res, max_dist, list(boxes) + [(tuple(world([c])[0]), (res * 0.5,) * 3) for c in final_points])
+    assert np.array_equal(g.d2(), host.d2)
+
+
+def test_one_point_at_512_cube_is_a_window_not_the_grid():
+    """cfg 5's grid (512^3 @ 0.01 m): one more point recomputes (2 dmax + 1)^3 cells, not 134 M; the result equals a full
+    rebuild; refused inputs leave the field alone."""
+    import time
+    from smpl_amd import capi
+    cfg = scenes.config5()
+    gr = cfg.grid
+    g = capi.Grid.from_boxes(gr.origin, gr.dims, gr.res, gr.max_dist, cfg.boxes)
+    dmax = int(np.ceil(gr.max_dist / gr.res))
+    p = np.asarray(gr.origin) + np.array([[256, 200, 300]]) * gr.res
+    g.add_points(p)                                                              # (first call: allocations, kernel load)
+    g.remove_points(p)
+    t0 = time.perf_counter()
+    g.add_points(p)
+    dt = time.perf_counter() - t0
+    assert g.last_edit_cells() == (2 * dmax + 1) ** 3
+    assert dt < 0.02, dt                                                         # milliseconds, against ~17 ms for three full passes
+    full = capi.Grid.from_boxes(gr.origin, gr.dims, gr.res, gr.max_dist, cfg.boxes)
+    full.add_points(p)
+    assert np.array_equal(g.d2(), full.d2())
+    with pytest.raises(capi.SmplxError) as err:
+        g.add_points(np.array([[np.nan, 0.0, 0.0]]))
+    assert err.value.code == -1
+    with pytest.raises(capi.SmplxError):
+        g.add_boxes([((np.inf, 0.0, 0.0), (0.1, 0.1, 0.1))])
+    assert np.array_equal(g.d2(), full.d2())
+
+
+def test_an_edited_grid_asks_its_spaces_for_a_new_goal(small_cfg):
+    """A space caches successor lists: after an edit of its grid GetSuccs / plan refuse (SMPLX_E_STATE) until the goal is set
+    again; collision queries read the edited field at once."""
+    from smpl_amd import capi
+    cfg = small_cfg
+    gr = cfg.grid
+    grid = capi.Grid.from_boxes(gr.origin, gr.dims, gr.res, gr.max_dist, cfg.boxes)
+    model = capi.Model(cfg.robot_text)
+    s = capi.Space(model, grid, cfg.mprim, cfg.params, 256)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    sid = s.set_start(cfg.start)
+    assert len(s.get_succs(sid)[0]) > 0
+    assert s.state_valid_batch(np.array([cfg.start]))[0][0] == 1
+    # an obstacle on the arm's forearm at the start configuration
+    fk = s.sphere_positions(np.array([cfg.start]))[0]
+    grid.add_points(fk[-1:])
+    assert s.state_valid_batch(np.array([cfg.start]))[0][0] == 0                  # the checker sees it at once
+    with pytest.raises(capi.SmplxError) as err:
+        s.get_succs(sid)
+    assert err.value.code == -5
+    with pytest.raises(capi.SmplxError):
+        s.plan(5.0, 1.0, 1.0, True, True, 100, 100)
+    grid.remove_points(fk[-1:])
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    sid = s.set_start(cfg.start)
+    assert len(s.get_succs(sid)[0]) > 0
