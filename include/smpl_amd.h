@@ -191,8 +191,7 @@ int smplx_bfs_metric_start_distance(smplx_space* s, const double* xyz, int n, do
 /* the padded (nx+2)(ny+2)(nz+2) BFS_3D distance grid, node order of bfs3d.h:213-220 */
 int64_t smplx_bfs_size(const smplx_space* s);
 int smplx_bfs_copy(smplx_space* s, int32_t* out);
-/* passes the last BFS took: sweeps over the flagged 8x8x8 bricks (default), or BFS levels with env SMPLX_BFS=levels
- * (the level-synchronous kernel, kept for A/B runs) */
+/* passes the last BFS took: sweeps over the queued 8x8x8 bricks (the device keeps the grid in brick-major records) */
 int smplx_bfs_levels(const smplx_space* s);
 
 /* ---- ManipLattice (smpl/include/smpl/graph/manip_lattice.h:63-307) ---- */

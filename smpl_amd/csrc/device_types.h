@@ -88,10 +88,27 @@ struct SmplxGridDev {
     const uint16_t* d2;           // brick-tiled squared cell distances
 };
 
+// BFS_3D distance grid (bfs3d.h:213-220 holds it as a padded x-fastest array) in BRICK-MAJOR records: an 8x8x8 brick of
+// cells is one 4 KB record -- its 512 cells, then copies of its six faces, then of its four z-parallel edges -- so that a
+// brick sweep (k_bfs_brick_wave) reads its own cells in one run and every piece of its one-cell halo as a contiguous run of
+// a neighbour's record (the x-fastest array gave it 100 rows of 40 bytes: 12x the algorithmic traffic, round 2).
+//   [0, 512)     cell (lx, ly, lz) at lz * 64 + ly * 8 + lx
+//   [512, 896)   faces x = 0, x = 7 (index lz * 8 + ly), y = 0, y = 7 (lz * 8 + lx), z = 0, z = 7 (ly * 8 + lx), 64 each
+//   [896, 928)   edges (x, y) = (0, 0), (7, 0), (0, 7), (7, 7), index lz
+// WALL 0x7FFFFFFF, UNDISCOVERED -1 as in the reference (bfs3d.h:48-51); cells beyond the grid in the last bricks are walls.
+// A distance carries the TAG of the BFS run that wrote it in its bits 28-30 (tag_word = tag << 28, tag 1..7, tag_mask =
+// 0xF0000000): a cell whose tag is not the current run's counts as UNDISCOVERED, so a new goal needs no pass over the records
+// to reset them (BFS_3D::run's reset loop, bfs3d.cpp:162-166, was a tenth of a goal at 512^3) except every seventh, when the
+// tags wrap.  -1 reads as tag 15, which no run has.  Grids of 2^28 cells or more run with tag_mask = 0 and a reset per goal.
+#define SMPLX_BFS_REC 1024
+#define SMPLX_BFS_FACES 512
+#define SMPLX_BFS_EDGES 896
+#define SMPLX_BFS_USED 928
 struct SmplxBfsDev {
-    int32_t dim_x, dim_y, dim_z, dim_xy;     // padded dims (bfs3d.cpp:61-66)
-    int32_t cost_per_cell, pad;
-    const int32_t* dist;                      // (nx+2)(ny+2)(nz+2), WALL 0x7FFFFFFF, UNDISCOVERED -1
+    int32_t dim_x, dim_y, dim_z, dim_xy;     // padded dims (bfs3d.cpp:61-66): what inBounds compares with
+    int32_t cost_per_cell, tag_word;
+    int32_t nbx, nby, nbz, tag_mask;         // bricks per axis
+    const int32_t* dist;                      // nbx * nby * nbz records
 };
 
 struct SmplxActionsDev {

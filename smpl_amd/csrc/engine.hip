@@ -25,6 +25,9 @@
 #include "model_compile.h"
 #include "specialize.h"
 #include "test_hooks.h"
+#ifdef SMPLX_BFS_TRACE
+extern __device__ long long g_bfs_trace[16];
+#endif
 
 namespace {
 
@@ -217,15 +220,16 @@ struct smplx_space {
     int lds_nroot = 0;   // root-position slots per thread in LDS: none in the per-robot build (they live in registers there)
     // BFS
     int32_t* d_bfs = nullptr;
-    int32_t* d_queue[2] = {nullptr, nullptr};   // brick lists of the two passes in flight (level mode: the two frontier queues)
+    int32_t* d_queue = nullptr;                 // brick lists of the two passes in flight
     int32_t* d_counts = nullptr;
-    unsigned char* d_brick_flags = nullptr;     // brick mode: bricks whose halo changed in the current pass
     int32_t* d_brick_queued = nullptr;          // wave-per-brick mode: 2 x nbricks "queued for the next pass" words
-    bool bfs_level_mode = false;                // SMPLX_BFS=levels: the level-synchronous kernel of round 1 (A/B runs)
-    bool bfs_block_mode = false;       // SMPLX_BFS=blocks: the block-per-brick sweep kernel instead of the wave-per-brick one
     int bfs_bricks[3] = {0, 0, 0};
     int32_t* d_minus_one = nullptr;   // a device int holding -1 (k_expand: deferred pass without a counter)
-    int64_t bfs_total = 0;
+    int64_t bfs_total = 0;                      // cells of the padded grid the API hands out (smplx_bfs_copy)
+    int64_t bfs_ints = 0;                       // ints of the brick-major records on the device
+    bool bfs_reset_due = false;
+    int bfs_tag = 0;                            // tag of the last BFS run (device_types.h SmplxBfsDev), 0 before the first
+    std::vector<int32_t> bfs_queue_sizes;       // bricks queued in every pass of the last BFS: sizes the next goal's launches
     int bfs_levels = 0;
     int wall_thr = -1;
     bool goal_set = false;
@@ -369,99 +373,103 @@ int run_heuristic(smplx_space* s, const double* q, int n, int32_t* h, double* xy
     return SMPLX_OK;
 }
 
-// BFS_3D::run to completion on the device (bfs3d.cpp:156-201, 507-547)
+constexpr int kBfsHistory = 2048;   // passes whose queue sizes are kept behind the counters (d_counts)
+
+// BFS_3D::run to completion on the device (bfs3d.cpp:156-201, 507-547): passes over the queued 8x8x8 bricks until none is
+// queued (kernels.hip k_bfs_brick_wave)
 int run_bfs(smplx_space* s, const double xyz[3])
 {
     const smplx_grid* g = s->grid;
     int c[3];
     for (int a = 0; a < 3; ++a) c[a] = (int)(g->dev.inv_res * (xyz[a] - g->dev.origin_minus_res[a]) + 0.5) - 1;
-    const int dx = g->n[0] + 2, dy = g->n[1] + 2;
-    hipLaunchKernelGGL(k_bfs_reset, dim3(2048), dim3(256), 0, s->stream, s->d_bfs, (size_t)s->bfs_total);
-    HIP_TRY(hipGetLastError());
+    // BFS_3D::run's reset (bfs3d.cpp:162-166): the run's tag makes every other run's distances UNDISCOVERED; a pass over
+    // the records only when the tags wrap (finish_goal chose the tag and uploaded it)
+    if (s->bfs_reset_due) {
+        hipLaunchKernelGGL(k_bfs_reset, dim3(2048), dim3(256), 0, s->stream, s->d_bfs, (size_t)s->bfs_ints);
+        HIP_TRY(hipGetLastError());
+        s->bfs_reset_due = false;
+    }
+    const int tag_word = s->hs.bfs.tag_word, tag_mask = s->hs.bfs.tag_mask;
     s->bfs_levels = 0;
     const bool in_bounds = !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->n[0] || c[1] >= g->n[1] || c[2] >= g->n[2]);
     if (!in_bounds) {   // bfs3d.cpp:169-171: nothing is labelled
         HIP_TRY(hipStreamSynchronize(s->stream));
         return SMPLX_OK;
     }
-    const int origin = (c[2] + 1) * dx * dy + (c[1] + 1) * dx + (c[0] + 1);
-    if (!s->bfs_level_mode) {
-        // brick formulation (kernels.hip k_bfs_brick): passes over the flagged 8x8x8 bricks until none is flagged
-        const int nbx = s->bfs_bricks[0], nby = s->bfs_bricks[1], nbz = s->bfs_bricks[2];
-        const int nbricks = nbx * nby * nbz;
-        const int dz = g->n[2] + 2;
-        const int brick = ((c[2] / 8) * nby + (c[1] / 8)) * nbx + (c[0] / 8);
-        // two activation lists alternate, each cut into 16 sub-lists of nbricks entries with their own counters on separate
-        // lines: d_queue[0] holds the lists, d_counts the 2 x 16 counters
-        const int kShards = 16;
-        const size_t list_ints = (size_t)kShards * nbricks;
-        int32_t* lists = s->d_queue[0];
-        hipLaunchKernelGGL(k_bfs_brick_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, (size_t)origin, brick, lists, s->d_counts);
-        HIP_TRY(hipGetLastError());
-        const int grid = std::min(nbricks, 4096);
-        int pass = 0;
-        std::vector<int32_t> cnt(3 * kShards * 32);
-        // wave mode: three counter sets rotate (in, next, zeroed for the pass after), two "queued" arrays alternate
-        int32_t* queued[2] = {s->d_brick_queued, s->d_brick_queued + nbricks};
-        // blocks per pass: every block of a launch reads the counters even when it has no brick, so a launch of 16 384
-        // mostly idle blocks costs ~5 us; in the tail (fewer than 256 bricks flagged) 2 048 do
-        int wave_grid_max = 16384;
-        int wave_grid = wave_grid_max;   // (2 048 for the first chunk was tried: the front passes 2 048 bricks by pass 10 -- slower)
-        // passes are enqueued in chunks with one look at the counters per chunk: 16 while the front is wide, 4 once fewer
-        // than 256 bricks are flagged (the tail of a BFS is a handful of bricks per pass: a look costs about two empty
-        // passes, a chunk of 16 wasted eight of them on average)
-        int chunk = 16;
-        while (true) {
-            for (int k = 0; k < chunk; ++k, ++pass) {
-                const int in = pass & 1, out = (pass + 1) & 1;
-                if (s->bfs_block_mode)   // SMPLX_BFS=blocks: one 512-thread block per brick (kept for A/B runs)
-                    hipLaunchKernelGGL(k_bfs_brick, dim3(grid), dim3(512), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
-                                       lists + in * list_ints, s->d_counts + in * kShards * 32, s->d_counts + out * kShards * 32, nbricks,
-                                       s->d_brick_flags);
-                else {                   // one wave per brick; the pass appends to the next list itself
-                    const int c_in = pass % 3, c_next = (pass + 1) % 3, c_after = (pass + 2) % 3;
-                    hipLaunchKernelGGL(k_bfs_brick_wave, dim3(std::min(nbricks, wave_grid)), dim3(64), 0, s->stream, s->d_bfs, dx, dy, dz, nbx, nby, nbz,
-                                       lists + in * list_ints, s->d_counts + c_in * kShards * 32, lists + out * list_ints,
-                                       s->d_counts + c_next * kShards * 32, s->d_counts + c_after * kShards * 32, nbricks,
-                                       queued[in], queued[out]);
-                    continue;
-                }
-                hipLaunchKernelGGL(k_bfs_compact, dim3(blocks_for(nbricks, 256)), dim3(256), 0, s->stream, s->d_brick_flags, nbricks,
-                                   lists + out * list_ints, s->d_counts + out * kShards * 32, nbricks);
-            }
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(cnt.data(), s->d_counts, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            long pending = 0;
-            const int set = s->bfs_block_mode ? (pass & 1) : pass % 3;   // the "in" counters of the pass that would come next
-            for (int k = 0; k < kShards; ++k) pending += cnt[(size_t)set * kShards * 32 + 32 * k];
-            if (pending == 0) break;
-            chunk = pending < 256 ? 4 : 16;
-            wave_grid = pending < 256 ? std::min(wave_grid_max, 2048) : wave_grid_max;
-            // (a label-correcting brick sweep can legitimately need on the order of nbricks passes on maze-like free space)
-            if (pass > 4 * nbricks + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
-        }
-        s->bfs_levels = pass;
-        return SMPLX_OK;
-    }
-    hipLaunchKernelGGL(k_bfs_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, origin, s->d_queue[0], s->d_counts);
+    const int nbx = s->bfs_bricks[0], nby = s->bfs_bricks[1], nbz = s->bfs_bricks[2];
+    const int nbricks = nbx * nby * nbz;
+    // two brick lists alternate, each cut into 16 sub-lists of nbricks entries with their own counters on separate
+    // lines: d_queue holds the lists, d_counts the 3 x 16 counters (in / next / zeroed for the pass after)
+    const int kShards = 16;
+    const size_t list_ints = (size_t)kShards * nbricks;
+    int32_t* lists = s->d_queue;
+    hipLaunchKernelGGL(k_bfs_brick_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, c[0], c[1], c[2], nbx, nby, lists, s->d_counts, tag_word);
     HIP_TRY(hipGetLastError());
-    int level = 0;
-    int32_t counts[3];
-    const int chunk = 32;
+    int pass = 0;
+    std::vector<int32_t> cnt(3 * kShards * 32 + kBfsHistory);
+    int32_t* queued[2] = {s->d_brick_queued, s->d_brick_queued + nbricks};
+    int32_t* d_history = s->d_counts + 3 * kShards * 32;
+    // Launch sizes.  Every block of a launch reads the counters even when it has no brick (16 384 mostly idle blocks cost
+    // ~6 us, 2 048 ~2.4 us), and every look at the counters from the host costs ~40 us (copy, synchronise, the stream
+    // running dry).  The passes of two goals in one grid are much alike, so the queue sizes of the last BFS (kept by
+    // the kernel behind the counters) size this one: all its passes plus two are enqueued at once, each with twice
+    // the blocks its neighbourhood of passes had bricks, and the one look at the end usually finds nothing queued.  A first BFS
+    // -- or one that outlives the plan -- goes in chunks: 16 passes while the front is wide, 4 once fewer than 256 bricks
+    // are queued (the tail is a narrow front: a chunk of 16 wasted eight passes on average).
+    const std::vector<int32_t> plan = s->bfs_queue_sizes;
+    int planned = 0;
+    for (size_t k = 0; k < plan.size(); ++k) if (plan[k] > 0) planned = (int)k + 1;
+    const int wave_grid_max = 16384;
+    int wave_grid = planned > 0 ? 2048 : wave_grid_max;    // (past the plan: its tail)
+    int chunk = planned > 0 ? planned + 2 : 16;
+    const bool dbg = getenv("SMPLX_DEBUG_TIMING") != nullptr;
+    if (dbg) chunk = 1;     // one look at the counters per pass: bricks and microseconds of every pass on stderr
+    auto grid_of = [&](int p) {
+        if (p >= planned) return wave_grid;
+        int m = 0;
+        for (int k = std::max(0, p - 1); k <= std::min(planned - 1, p + 1); ++k) m = std::max(m, plan[k]);
+        return std::min(wave_grid_max, std::max(1024, 2 * m));
+    };
     while (true) {
-        for (int k = 0; k < chunk; ++k, ++level) {
-            hipLaunchKernelGGL(k_bfs_level, dim3(512), dim3(512), 0, s->stream, s->d_bfs, s->d_queue[level & 1],
-                               s->d_queue[(level + 1) & 1], s->d_counts, level, dx, dx * dy);
+        const auto tp0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < chunk; ++k, ++pass) {
+            const int in = pass & 1, out = (pass + 1) & 1;
+            const int c_in = pass % 3, c_next = (pass + 1) % 3, c_after = (pass + 2) % 3;
+            hipLaunchKernelGGL(k_bfs_brick_wave, dim3(std::min(nbricks, grid_of(pass))), dim3(64), 0, s->stream, s->d_bfs, nbx, nby, nbz,
+                               lists + in * list_ints, s->d_counts + c_in * kShards * 32, lists + out * list_ints,
+                               s->d_counts + c_next * kShards * 32, s->d_counts + c_after * kShards * 32, nbricks,
+                               queued[in], queued[out], pass < kBfsHistory ? d_history + pass : (int32_t*)nullptr, tag_word, tag_mask);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(counts, s->d_counts, sizeof(counts), hipMemcpyDeviceToHost, s->stream));
+        const size_t look = 3 * kShards * 32 + (size_t)std::min(pass, kBfsHistory);
+        HIP_TRY(hipMemcpyAsync(cnt.data(), s->d_counts, sizeof(int32_t) * look, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        // frontier that the next launch would consume
-        if (counts[level % 3] == 0) break;
-        if (level > s->bfs_total) return set_error(SMPLX_E_HIP, "BFS did not terminate");
+        long pending = 0;
+        const int set = pass % 3;   // the "in" counters of the pass that would come next
+        for (int k = 0; k < kShards; ++k) pending += cnt[(size_t)set * kShards * 32 + 32 * k];
+        if (dbg) {
+            fprintf(stderr, "[smplx bfs] pass %d: %.1f us (launch + sync), %ld bricks queued for the next\n", pass - 1,
+                    1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count(), pending);
+#ifdef SMPLX_BFS_TRACE
+            {
+                long long tr[16], zero[16] = {0};
+                if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_bfs_trace), sizeof(tr)) == hipSuccess && tr[7] > 0) {
+                    static const char* names[7] = {"", "list", "tile load", "sweeps", "stores", "requeue test", "claim"};
+                    fprintf(stderr, "[smplx bfs]   %lld visits, longest / mean (us):", tr[7]);
+                    for (int k = 1; k < 7; ++k) fprintf(stderr, " %s %.2f / %.2f%s", names[k], 0.01 * tr[k], 0.01 * tr[8 + k] / tr[7], k < 6 ? "," : "\n");
+                }
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bfs_trace), zero, sizeof(zero));
+            }
+#endif
+        }
+        if (pending == 0) break;
+        if (!dbg) chunk = pending < 256 ? 4 : 16;
+        wave_grid = pending < 256 ? std::min(wave_grid_max, 2048) : wave_grid_max;
+        // (a label-correcting brick sweep can legitimately need on the order of nbricks passes on maze-like free space)
+        if (pass > 4 * nbricks + 1024) return set_error(SMPLX_E_HIP, "BFS did not terminate");
     }
-    s->bfs_levels = level;
+    s->bfs_queue_sizes.assign(cnt.begin() + 3 * kShards * 32, cnt.begin() + 3 * kShards * 32 + std::min(pass, kBfsHistory));
+    s->bfs_levels = pass;
     return SMPLX_OK;
 }
 
@@ -1276,29 +1284,24 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
     const int dx = grid->n[0] + 2, dy = grid->n[1] + 2, dz = grid->n[2] + 2;
     s->bfs_total = (int64_t)dx * dy * dz;
-    {
-        const char* env = getenv("SMPLX_BFS");
-        s->bfs_level_mode = env && std::strcmp(env, "levels") == 0;
-        s->bfs_block_mode = env && std::strcmp(env, "blocks") == 0;
-    }
     for (int a = 0; a < 3; ++a) s->bfs_bricks[a] = (grid->n[a] + 7) / 8;
     const size_t nbricks = (size_t)s->bfs_bricks[0] * s->bfs_bricks[1] * s->bfs_bricks[2];
-    const size_t qn = s->bfs_level_mode ? (size_t)grid->n[0] * grid->n[1] * grid->n[2] + 64 : 2 * 16 * nbricks + 64;
-    if ((e = hipMalloc((void**)&s->d_bfs, sizeof(int32_t) * s->bfs_total)) != hipSuccess) return bail(e, "hipMalloc bfs");
-    if ((e = hipMalloc((void**)&s->d_brick_flags, nbricks + 64)) != hipSuccess) return bail(e, "hipMalloc bfs flags");
-    if ((e = hipMemset(s->d_brick_flags, 0, nbricks + 64)) != hipSuccess) return bail(e, "hipMemset bfs flags");
+    s->bfs_ints = (int64_t)nbricks * SMPLX_BFS_REC;
+    if ((e = hipMalloc((void**)&s->d_bfs, sizeof(int32_t) * s->bfs_ints)) != hipSuccess) return bail(e, "hipMalloc bfs");
     if ((e = hipMalloc((void**)&s->d_brick_queued, sizeof(int32_t) * 2 * nbricks + 64)) != hipSuccess) return bail(e, "hipMalloc bfs queued");
     if ((e = hipMemset(s->d_brick_queued, 0, sizeof(int32_t) * 2 * nbricks + 64)) != hipSuccess) return bail(e, "hipMemset bfs queued");
-    if ((e = hipMalloc((void**)&s->d_queue[0], sizeof(int32_t) * qn)) != hipSuccess) return bail(e, "hipMalloc bfs queue");
-    if ((e = hipMalloc((void**)&s->d_queue[1], sizeof(int32_t) * (s->bfs_level_mode ? qn : 64))) != hipSuccess) return bail(e, "hipMalloc bfs queue");
-    if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * (3 * 16 * 32 + 4))) != hipSuccess) return bail(e, "hipMalloc bfs counts");
+    if ((e = hipMalloc((void**)&s->d_queue, sizeof(int32_t) * (2 * 16 * nbricks + 64))) != hipSuccess) return bail(e, "hipMalloc bfs queue");
+    if ((e = hipMalloc((void**)&s->d_counts, sizeof(int32_t) * (3 * 16 * 32 + kBfsHistory))) != hipSuccess) return bail(e, "hipMalloc bfs counts");
     if ((e = hipMalloc((void**)&s->d_minus_one, sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc");
     { const int32_t m1 = -1; if ((e = hipMemcpy(s->d_minus_one, &m1, sizeof(m1), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy"); }
     s->hs.bfs.dim_x = dx; s->hs.bfs.dim_y = dy; s->hs.bfs.dim_z = dz; s->hs.bfs.dim_xy = dx * dy;
     s->hs.bfs.cost_per_cell = params->cost_per_cell;
+    s->hs.bfs.nbx = s->bfs_bricks[0]; s->hs.bfs.nby = s->bfs_bricks[1]; s->hs.bfs.nbz = s->bfs_bricks[2];
     s->hs.bfs.dist = s->d_bfs;
+    s->hs.bfs.tag_mask = (int64_t)grid->n[0] * grid->n[1] * grid->n[2] < ((int64_t)1 << 28) ? (int32_t)0xF0000000u : 0;
+    s->hs.bfs.tag_word = 0;
     // BfsHeuristic::syncGridAndBfs (bfs_heuristic.cpp:331-353), once, at init
-    hipLaunchKernelGGL(k_bfs_init, dim3(2048), dim3(256), 0, s->stream, grid->dev, s->wall_thr, dx, dy, dz, s->d_bfs);
+    hipLaunchKernelGGL(k_bfs_init, dim3(2048), dim3(256), 0, s->stream, grid->dev, s->wall_thr, s->bfs_bricks[0], s->bfs_bricks[1], s->bfs_bricks[2], s->d_bfs);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_bfs_init");
     {
         // Device copy of the state table (K5).  The K5 entry points and smplx_table_sync create it on first use.  The
@@ -1324,10 +1327,8 @@ void smplx_space_destroy(smplx_space* s)
     if (s->batch_done) (void)hipEventDestroy(s->batch_done);
     if (s->d_space) (void)hipFree(s->d_space);
     if (s->d_bfs) (void)hipFree(s->d_bfs);
-    if (s->d_queue[0]) (void)hipFree(s->d_queue[0]);
-    if (s->d_queue[1]) (void)hipFree(s->d_queue[1]);
+    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->d_counts) (void)hipFree(s->d_counts);
-    if (s->d_brick_flags) (void)hipFree(s->d_brick_flags);
     if (s->d_brick_queued) (void)hipFree(s->d_brick_queued);
     if (s->d_minus_one) (void)hipFree(s->d_minus_one);
     if (s->d_table) (void)hipFree(s->d_table);
@@ -1514,6 +1515,16 @@ int smplx_cc_sphere_positions(smplx_space* s, const double* q, int n, double* ou
 static int finish_goal(smplx_space* s)
 {
     for (int a = 0; a < 3; ++a) s->hs.goal.xyz[a] = s->goal_xyz[a];
+    // the tag of this goal's BFS run (device_types.h SmplxBfsDev): 1..7, a reset of the records when they wrap
+    if (s->hs.bfs.tag_mask != 0) {
+        s->bfs_reset_due = s->bfs_tag == 7;
+        s->bfs_tag = s->bfs_tag % 7 + 1;
+        s->hs.bfs.tag_word = s->bfs_tag << 28;
+    } else {
+        s->bfs_reset_due = s->bfs_tag != 0;
+        s->bfs_tag = 1;
+        s->hs.bfs.tag_word = 0;
+    }
     if (int e = upload_space(s)) return e;
     if (int e = run_bfs(s, s->goal_xyz)) return e;
     s->goal_set = true;
@@ -1574,8 +1585,15 @@ int smplx_bfs_levels(const smplx_space* s) { return s ? s->bfs_levels : 0; }
 int smplx_bfs_copy(smplx_space* s, int32_t* out)
 {
     if (!s || !out) return set_error(SMPLX_E_ARG, "null argument");
-    HIP_TRY(hipMemcpyAsync(out, s->d_bfs, sizeof(int32_t) * s->bfs_total, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    // the device keeps brick-major records (device_types.h SmplxBfsDev); what goes out is the reference's padded array
+    int32_t* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, sizeof(int32_t) * s->bfs_total));
+    hipLaunchKernelGGL(k_bfs_export, dim3(2048), dim3(256), 0, s->stream, s->hs.bfs, tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, sizeof(int32_t) * s->bfs_total, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return set_error(SMPLX_E_HIP, std::string("smplx_bfs_copy: ") + hipGetErrorString(e));
     return SMPLX_OK;
 }
 

@@ -69,15 +69,10 @@ __global__ void k_heuristic(const SmplxSpaceDev* S, const double* Q, int n, int*
 __global__ void k_sphere_positions(const SmplxSpaceDev* S, const double* Q, int n, double* out);
 __global__ void k_table_insert(const SmplxSpaceDev* S, const SmplxSpaceDev* const* stab, const int* items, int n, int nvars);
 __global__ void k_bfs_metric(SmplxGridDev grid, SmplxBfsDev bfs, const double* xyz, int n, double* out);
-__global__ void k_bfs_init(SmplxGridDev g, int wall_thr, int dim_x, int dim_y, int dim_z, int* dist);
+__global__ void k_bfs_init(SmplxGridDev g, int wall_thr, int nbx, int nby, int nbz, int* dist);
 __global__ void k_bfs_reset(int* dist, size_t total);
-__global__ void k_bfs_seed(int* dist, int origin, int* queue, int* counts);
-__global__ void k_bfs_level(int* dist, const int* q_in, int* q_out, int* counts, int level, int dim_x, int dim_xy);
-__global__ void k_bfs_brick(int* dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz, const int* list_in,
-                            const int* counts_in, int* counts_next, int shard_cap, unsigned char* flags);
-__global__ void k_bfs_brick_wave(int* dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz, const int* list_in,
-                                 const int* counts_in, int* list_next, int* counts_next, int* counts_after, int shard_cap,
-                                 int* queued_mine, int* queued_next);
-__global__ void k_bfs_compact(unsigned char* flags, int nbricks, int* list_out, int* counts_out, int shard_cap);
-__global__ void k_bfs_brick_seed(int* dist, size_t origin, int brick, int* list0, int* counts);
+__global__ void k_bfs_export(SmplxBfsDev b, int* out);
+__global__ void k_bfs_brick_seed(int* dist, int cx, int cy, int cz, int nbx, int nby, int* list0, int* counts, int tag_word);
+__global__ void k_bfs_brick_wave(int* dist, int nbx, int nby, int nbz, const int* list_in, const int* counts_in, int* list_next,
+                                 int* counts_next, int* counts_after, int shard_cap, int* queued_mine, int* queued_next, int* queue_size_out, int tag_word, int tag_mask);
 }

@@ -920,7 +920,10 @@ __device__ __forceinline__ bool bfs_in_bounds(const SmplxBfsDev& b, const int c[
 }
 __device__ __forceinline__ int bfs_dist(const SmplxBfsDev& b, const int c[3])
 {
-    return b.dist[(size_t)(c[2] + 1) * b.dim_xy + (size_t)(c[1] + 1) * b.dim_x + (c[0] + 1)];
+    const size_t brick = ((size_t)(c[2] >> 3) * b.nby + (c[1] >> 3)) * b.nbx + (c[0] >> 3);
+    const int v = b.dist[brick * SMPLX_BFS_REC + ((c[2] & 7) << 6) + ((c[1] & 7) << 3) + (c[0] & 7)];
+    if (v == 0x7FFFFFFF) return v;
+    return ((v ^ b.tag_word) & b.tag_mask) != 0 ? -1 : (v & ~b.tag_mask);     // another run's value: UNDISCOVERED
 }
 
 // BfsHeuristic::getBfsCostToGoal (bfs_heuristic.cpp:355-366)
@@ -2171,30 +2174,115 @@ k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
-// BFS-3D (bfs3d.cpp:156-201 run, 507-547 search).  Level-synchronous: one launch expands the
-// whole frontier of distance d into the frontier of distance d+1.  Labels are exact BFS hop
-// counts whatever the order inside a level, so the result equals the sequential queue's.
+// BFS-3D (bfs3d.cpp:156-201 run, 507-547 search), brick formulation over brick-major records (device_types.h
+// SmplxBfsDev).  A wave owns an 8x8x8 brick: it loads the brick and its one-cell halo into LDS ONCE, relaxes
+// d(c) = min(d(c), min over the 26 neighbours of d + 1) until nothing changes, writes the record back if anything improved,
+// and queues the neighbour bricks whose halo it changed.  A pass runs over the queued bricks; passes repeat until none is
+// queued.  Hop counts with unit edge costs are the unique fixed point of that relaxation from d(goal) = 0, so the grid equals
+// the sequential queue's (bfs3d.cpp:507-547) whatever order bricks are visited in: a brick that read a neighbour's old value
+// is queued again by that neighbour when the value drops.  (Round 1 ran one launch per BFS level, 192 at 256^3; round 2 the
+// bricks over the reference's x-fastest array.)
+// Sentinels as in the reference: WALL 0x7FFFFFFF never changes, UNDISCOVERED -1 stays -1 where no path leads.
 // ---------------------------------------------------------------------------------------------
+#define SMPLX_BFS_INF 0x7FFFFFFEu
+#define SMPLX_BFS_WALLV 0xFFFFFFFEu     // (not 0xFFFFFFFF: a wall + 1 must not wrap to 0 in the branch-free relaxation)
+#define SMPLX_BFS_SHARDS 16      // the brick list of a pass is cut into sub-lists with their counters on separate 128-byte lines
+
+#define SMPLX_BRICK 8
+#define SMPLX_BRICK_TILE (SMPLX_BRICK + 2)
+
+// local cell of slot s < SMPLX_BFS_USED of a record (interior, face copy or edge copy)
+__device__ __forceinline__ void bfs_slot_cell(int s, int& lx, int& ly, int& lz)
+{
+    if (s < SMPLX_BFS_FACES) { lz = s >> 6; ly = (s >> 3) & 7; lx = s & 7; return; }
+    if (s < SMPLX_BFS_EDGES) {
+        const int f = (s - SMPLX_BFS_FACES) >> 6, a = ((s - SMPLX_BFS_FACES) >> 3) & 7, c = (s - SMPLX_BFS_FACES) & 7;
+        if (f < 2) { lx = f == 0 ? 0 : 7; lz = a; ly = c; }
+        else if (f < 4) { ly = f == 2 ? 0 : 7; lz = a; lx = c; }
+        else { lz = f == 4 ? 0 : 7; ly = a; lx = c; }
+        return;
+    }
+    const int k = (s - SMPLX_BFS_EDGES) >> 3;
+    lz = (s - SMPLX_BFS_EDGES) & 7;
+    lx = (k & 1) ? 7 : 0;
+    ly = (k & 2) ? 7 : 0;
+}
+
+// every slot of a record that holds cell (lx, ly, lz) takes v
+__device__ __forceinline__ void bfs_record_store_cell(int* __restrict__ rec, int lx, int ly, int lz, int v)
+{
+    rec[(lz << 6) + (ly << 3) + lx] = v;
+    if (lx == 0) rec[SMPLX_BFS_FACES + 0 * 64 + lz * 8 + ly] = v;
+    if (lx == 7) rec[SMPLX_BFS_FACES + 1 * 64 + lz * 8 + ly] = v;
+    if (ly == 0) rec[SMPLX_BFS_FACES + 2 * 64 + lz * 8 + lx] = v;
+    if (ly == 7) rec[SMPLX_BFS_FACES + 3 * 64 + lz * 8 + lx] = v;
+    if (lz == 0) rec[SMPLX_BFS_FACES + 4 * 64 + ly * 8 + lx] = v;
+    if (lz == 7) rec[SMPLX_BFS_FACES + 5 * 64 + ly * 8 + lx] = v;
+    if ((lx == 0 || lx == 7) && (ly == 0 || ly == 7)) rec[SMPLX_BFS_EDGES + (((ly == 7) ? 2 : 0) + ((lx == 7) ? 1 : 0)) * 8 + lz] = v;
+}
+
+// Where the cells of a brick's 10x10x10 tile come from, and where the slots of its record sit in the tile: functions of the
+// position alone, so they are tables (the index arithmetic -- divisions by 10, a five-way case analysis -- was a fifth of a
+// lone brick's visit).  src[i] = offset in the source record | (dx + 1) << 10 | (dy + 1) << 12 | (dz + 1) << 14, (dx, dy, dz)
+// the neighbour brick the cell belongs to.  A halo cell comes from the neighbour's face copy whose fastest index is the
+// coordinate that varies along that piece of halo (rows of 8 contiguous ints), a z-parallel edge from the edge copies.
+struct BfsTileTables { unsigned short src[SMPLX_BRICK_TILE * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE]; unsigned short slot_tile[SMPLX_BFS_USED]; };
+constexpr BfsTileTables bfs_make_tables()
+{
+    BfsTileTables T{};
+    constexpr int TL = SMPLX_BRICK_TILE, TP = SMPLX_BRICK_TILE * SMPLX_BRICK_TILE;
+    for (int i = 0; i < TL * TL * TL; ++i) {
+        const int hx = i % TL, hy = (i / TL) % TL, hz = i / TP;
+        const int dx = hx == 0 ? -1 : (hx == TL - 1 ? 1 : 0), dy = hy == 0 ? -1 : (hy == TL - 1 ? 1 : 0), dz = hz == 0 ? -1 : (hz == TL - 1 ? 1 : 0);
+        const int lx = hx - 1 - 8 * dx, ly = hy - 1 - 8 * dy, lz = hz - 1 - 8 * dz;   // the neighbour's own cell
+        int off = SMPLX_BFS_FACES + (lz == 0 ? 4 : 5) * 64 + ly * 8 + lx;             // the z faces and the corners
+        if (dx != 0 && dy == 0) off = SMPLX_BFS_FACES + (lx == 0 ? 0 : 1) * 64 + lz * 8 + ly;      // y varies
+        if (dy != 0 && dx == 0) off = SMPLX_BFS_FACES + (ly == 0 ? 2 : 3) * 64 + lz * 8 + lx;      // x varies (a y face, or an x-parallel edge)
+        if (dx != 0 && dy != 0 && dz == 0) off = SMPLX_BFS_EDGES + (((ly == 7) ? 2 : 0) + ((lx == 7) ? 1 : 0)) * 8 + lz;
+        if (dx == 0 && dy == 0 && dz == 0) off = (lz << 6) + (ly << 3) + lx;
+        T.src[i] = (unsigned short)(off | ((dx + 1) << 10) | ((dy + 1) << 12) | ((dz + 1) << 14));
+    }
+    for (int s = 0; s < SMPLX_BFS_USED; ++s) {
+        int lx = 0, ly = 0, lz = 0;
+        if (s < SMPLX_BFS_FACES) { lz = s >> 6; ly = (s >> 3) & 7; lx = s & 7; }
+        else if (s < SMPLX_BFS_EDGES) {
+            const int f = (s - SMPLX_BFS_FACES) >> 6, a = ((s - SMPLX_BFS_FACES) >> 3) & 7, c = (s - SMPLX_BFS_FACES) & 7;
+            if (f < 2) { lx = f == 0 ? 0 : 7; lz = a; ly = c; }
+            else if (f < 4) { ly = f == 2 ? 0 : 7; lz = a; lx = c; }
+            else { lz = f == 4 ? 0 : 7; ly = a; lx = c; }
+        } else {
+            const int k = (s - SMPLX_BFS_EDGES) >> 3;
+            lz = (s - SMPLX_BFS_EDGES) & 7; lx = (k & 1) ? 7 : 0; ly = (k & 2) ? 7 : 0;
+        }
+        T.slot_tile[s] = (unsigned short)((lz + 1) * TP + (ly + 1) * TL + (lx + 1));
+    }
+    return T;
+}
+__constant__ BfsTileTables c_bfs_tables = bfs_make_tables();
 
 // walls: BfsHeuristic::syncGridAndBfs (bfs_heuristic.cpp:331-353) in integer form:
 // wall iff squared cell distance <= wall_thr (largest i with res*sqrt(i) <= radius; -1 if none)
 extern "C" __global__ void __launch_bounds__(256)
-k_bfs_init(SmplxGridDev g, int wall_thr, int dim_x, int dim_y, int dim_z, int* __restrict__ dist)
+k_bfs_init(SmplxGridDev g, int wall_thr, int nbx, int nby, int nbz, int* __restrict__ dist)
 {
-    const size_t total = (size_t)dim_x * dim_y * dim_z;
-    for (size_t node = (size_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (size_t)gridDim.x * 256) {
-        const int x = (int)(node % dim_x), y = (int)(node / dim_x % dim_y), z = (int)(node / ((size_t)dim_x * dim_y));
-        int v;
-        if (x == 0 || x == dim_x - 1 || y == 0 || y == dim_y - 1 || z == 0 || z == dim_z - 1) {
-            v = 0x7FFFFFFF;
-        } else {
-            const int cx = x - 1, cy = y - 1, cz = z - 1;
-            const size_t brick = ((size_t)(cx >> 2) * g.bricks[1] + (cy >> 2)) * g.bricks[2] + (cz >> 2);
-            const int d2 = (int)g.d2[brick * 64 + ((cx & 3) << 4) + ((cy & 3) << 2) + (cz & 3)];
-            v = d2 <= wall_thr ? 0x7FFFFFFF : -1;
+    const size_t total = (size_t)nbx * nby * nbz * SMPLX_BFS_REC;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int s = (int)(i % SMPLX_BFS_REC);
+        const size_t b = i / SMPLX_BFS_REC;
+        int v = 0x7FFFFFFF;
+        if (s < SMPLX_BFS_USED) {
+            int lx, ly, lz;
+            bfs_slot_cell(s, lx, ly, lz);
+            const int cx = (int)(b % nbx) * 8 + lx, cy = (int)(b / nbx % nby) * 8 + ly, cz = (int)(b / ((size_t)nbx * nby)) * 8 + lz;
+            if (cx < g.n[0] && cy < g.n[1] && cz < g.n[2]) {
+                const size_t brick = ((size_t)(cx >> 2) * g.bricks[1] + (cy >> 2)) * g.bricks[2] + (cz >> 2);
+                const int d2 = (int)g.d2[brick * 64 + ((cx & 3) << 4) + ((cy & 3) << 2) + (cz & 3)];
+                v = d2 <= wall_thr ? 0x7FFFFFFF : -1;
+            }
         }
-        dist[node] = v;
+        dist[i] = v;
     }
 }
 
@@ -2206,121 +2294,85 @@ k_bfs_reset(int* __restrict__ dist, size_t total)
         if (dist[node] != 0x7FFFFFFF) dist[node] = -1;
 }
 
+// the padded (nx+2)(ny+2)(nz+2) grid in the reference's node order (bfs3d.h:213-220), for smplx_bfs_copy
 extern "C" __global__ void __launch_bounds__(256)
-k_bfs_seed(int* __restrict__ dist, int origin, int* __restrict__ queue, int* __restrict__ counts)
+k_bfs_export(SmplxBfsDev b, int* __restrict__ out)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        dist[origin] = 0;      // overwrites a wall at the goal cell, as bfs3d.cpp:178 does
-        queue[0] = origin;
-        counts[0] = 1;
-        counts[1] = 0;
-        counts[2] = 0;
+    const size_t total = (size_t)b.dim_x * b.dim_y * b.dim_z;
+    for (size_t node = (size_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (size_t)gridDim.x * 256) {
+        const int x = (int)(node % b.dim_x), y = (int)(node / b.dim_x % b.dim_y), z = (int)(node / ((size_t)b.dim_x * b.dim_y));
+        int v = 0x7FFFFFFF;
+        if (!(x == 0 || x == b.dim_x - 1 || y == 0 || y == b.dim_y - 1 || z == 0 || z == b.dim_z - 1)) {
+            const int c[3] = {x - 1, y - 1, z - 1};
+            v = bfs_dist(b, c);
+        }
+        out[node] = v;
     }
 }
 
-// counts[level % 3] = size of the input frontier, counts[(level + 1) % 3] = size of the output frontier;
-// counts[(level + 2) % 3] (the previous input) is cleared here for the level after next.
-#define SMPLX_BFS_BLOCK 512
-
-extern "C" __global__ void __launch_bounds__(SMPLX_BFS_BLOCK)
-k_bfs_level(int* __restrict__ dist, const int* __restrict__ q_in, int* __restrict__ q_out, int* __restrict__ counts,
-            int level, int dim_x, int dim_xy)
-{
-    // Appending every discovered cell to the next frontier through one counter is what a level costs: same-address
-    // atomics serialise at ~12 ns, and even one per wave (the compiler's aggregation) is 5 000 of them on a 3*10^5-cell
-    // frontier.  So a thread keeps the cells it won in registers, the block adds up its threads' counts, claims ONE
-    // range of the queue, and every thread writes its cells into its part of the range.  (The order of the queue does
-    // not matter to the distances.)
-    __shared__ int wave_total[SMPLX_BFS_BLOCK / 64];
-    __shared__ int block_base;
-    const int n_in = counts[level % 3];
-    int* n_out = &counts[(level + 1) % 3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[(level + 2) % 3] = 0;
-    const int w = dim_x, p = dim_xy;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i0 = blockIdx.x * SMPLX_BFS_BLOCK; i0 < n_in; i0 += gridDim.x * SMPLX_BFS_BLOCK) {   // uniform per block
-        const int i = i0 + threadIdx.x;
-        int won[26];
-        int nwon = 0;
-        if (i < n_in) {
-            const int cur = q_in[i];
-#pragma unroll
-            for (int dz = -1; dz <= 1; ++dz) {
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (dx == 0 && dy == 0 && dz == 0) continue;
-                        const int nb = cur + dz * p + dy * w + dx;
-                        if (dist[nb] < 0 && atomicCAS(&dist[nb], -1, level + 1) == -1) won[nwon++] = nb;
-                    }
-                }
-            }
-        }
-        // exclusive prefix of nwon over the block
-        int incl = nwon;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wave_total[wv] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-#pragma unroll
-            for (int k = 0; k < SMPLX_BFS_BLOCK / 64; ++k) tot += wave_total[k];
-            block_base = tot > 0 ? atomicAdd(n_out, tot) : 0;
-        }
-        __syncthreads();
-        int first = block_base + incl - nwon;
-        for (int k = 0; k < wv; ++k) first += wave_total[k];
-        for (int k = 0; k < nwon; ++k) q_out[first + k] = won[k];
-        __syncthreads();   // wave_total / block_base are reused by the next round
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// BFS-3D, brick formulation (the default; the level-synchronous kernel above is kept for A/B runs).
-// The level kernel is bound by the sector traffic of its 26 scattered 4-byte probes per frontier cell
-// (~70 MB per level at 256^3).  Here a workgroup owns an 8x8x8 brick: it loads the brick and its one-cell
-// halo into LDS ONCE (4 KB), relaxes d(c) = min(d(c), min over the 26 neighbours of d + 1) inside LDS
-// until nothing changes, writes the cells that improved back with plain stores, and flags the neighbour
-// bricks whose halo it changed.  A pass runs over the flagged bricks; passes repeat until none is flagged.
-// Hop counts with unit edge costs are the unique fixed point of that relaxation from d(goal) = 0, so the
-// grid equals the sequential queue's (bfs3d.cpp:507-547) whatever order bricks are visited in: a brick
-// that read a neighbour's old value is re-flagged by that neighbour when the value drops.
-// Sentinels as in the reference: WALL 0x7FFFFFFF never changes, UNDISCOVERED -1 stays -1 where no path leads.
-// ---------------------------------------------------------------------------------------------
-#define SMPLX_BRICK 8
-#define SMPLX_BRICK_TILE (SMPLX_BRICK + 2)
-#define SMPLX_BFS_INF 0x7FFFFFFEu
-#define SMPLX_BFS_WALLV 0xFFFFFFFFu
-
-// Activation lists: a brick whose halo changed is FLAGGED with a plain byte store; between two passes k_bfs_compact turns
-// the flags into the next pass's list.  (Claiming bricks with atomic exchanges inside the pass -- no compaction launch --
-// was tried: it needs a release fence per visit and an L1-dropping acquire fence before every tile load, and took 7.1 ms
-// at 256^3 against 3.0 ms for this form.)  The list is cut into SMPLX_BFS_SHARDS sub-lists of `shard_cap` entries with
-// their counters on separate 128-byte lines (counts[32 k]): same-address atomics serialise at ~12 ns on this chip.
-#define SMPLX_BFS_SHARDS 16
-
-// One WAVE per brick (block = 64 lanes): lane (x, y) keeps its z-column of 8 cells in registers.  Against the block-per-
-// brick kernel below: no block barriers (a barrier of a one-wave block costs nothing), eight times as many bricks
-// resident per CU, and a change travels the whole column within one sweep (the z direction is relaxed in place, up
-// and down), so a brick needs a third of the sweeps.  In-plane neighbours come from the LDS tile, which the lanes
-// refresh with their columns at the start of every sweep; the halo (neighbour bricks' cells) is read once and never
-// changes during the sweeps.  Same fixed point as every label-correcting order: the BFS distances.
 extern "C" __global__ void __launch_bounds__(64)
-k_bfs_brick_wave(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz,
+k_bfs_brick_seed(int* __restrict__ dist, int cx, int cy, int cz, int nbx, int nby, int* __restrict__ list0, int* __restrict__ counts, int tag_word)
+{
+    // counts: 3 sets x SMPLX_BFS_SHARDS counters, 32 ints apart
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < 3 * SMPLX_BFS_SHARDS) counts[32 * t] = 0;
+        __syncthreads();
+        if (t == 0) {
+            const int brick = ((cz >> 3) * nby + (cy >> 3)) * nbx + (cx >> 3);
+            bfs_record_store_cell(dist + (size_t)brick * SMPLX_BFS_REC, cx & 7, cy & 7, cz & 7, tag_word);   // distance 0; overwrites a wall at the goal cell, as bfs3d.cpp:178 does
+            list0[0] = brick;      // sub-list 0 of list 0
+            counts[0] = 1;
+        }
+    }
+}
+
+// One WAVE per brick (block = 64 lanes): lane (x, y) keeps its z-column of 8 cells in registers: no block barriers, many bricks
+// resident per CU, and a change travels the whole column within one sweep (the z direction is relaxed in place, up and
+// down), so a brick needs a third of the sweeps of a cell-per-thread version.  In-plane neighbours come from the LDS tile, which
+// the lanes refresh with their columns at the start of every sweep; the halo (neighbour bricks' cells) is read once and
+// never changes during the sweeps.
+// The pass builds the next pass's brick list itself: a neighbour brick is claimed with an atomic exchange on its "queued for the
+// next pass" word and appended by the claimer.  Two queued-arrays alternate: a brick clears its own word of the array it was
+// queued in, so that array is clean again when it next serves as "next".  Three counter sets rotate (in / next / the one zeroed
+// for the pass after).
+// Lane shifts of the brick kernel: lane t = ty * 8 + tx holds the z-column at (tx, ty).  A lane outside the brick's 8x8
+// contributes SMPLX_BFS_WALLV, which never wins a minimum.
+struct BfsLanes { bool has_left, has_right, has_up, has_down; int up_addr, down_addr; };
+__device__ __forceinline__ unsigned int bfs_min(unsigned int a, unsigned int b) { return a < b ? a : b; }
+// min over the lane and its x neighbours (DPP row_shr:1 / row_shl:1 within the 16-lane row: rows of 8 never straddle one)
+__device__ __forceinline__ unsigned int bfs_window_x(const BfsLanes& W, unsigned int x)
+{
+    const unsigned int l = (unsigned int)__builtin_amdgcn_update_dpp((int)SMPLX_BFS_WALLV, (int)x, 0x111, 0xf, 0xf, false);
+    const unsigned int r = (unsigned int)__builtin_amdgcn_update_dpp((int)SMPLX_BFS_WALLV, (int)x, 0x101, 0xf, 0xf, false);
+    return bfs_min(x, bfs_min(W.has_left ? l : SMPLX_BFS_WALLV, W.has_right ? r : SMPLX_BFS_WALLV));
+}
+// min over the lane and its y neighbours (lanes t - 8 and t + 8)
+__device__ __forceinline__ unsigned int bfs_window_y(const BfsLanes& W, unsigned int x)
+{
+    const unsigned int u = (unsigned int)__builtin_amdgcn_ds_bpermute(W.up_addr, (int)x);
+    const unsigned int d = (unsigned int)__builtin_amdgcn_ds_bpermute(W.down_addr, (int)x);
+    return bfs_min(x, bfs_min(W.has_up ? u : SMPLX_BFS_WALLV, W.has_down ? d : SMPLX_BFS_WALLV));
+}
+
+#ifdef SMPLX_BFS_TRACE
+// diagnostic build (tools/bfs_trace.sh): every visit leaves the 100 MHz wall clock at its phase boundaries; the longest and
+// the sum of each phase over the visits of a pass go to g_bfs_trace[k] / [8 + k], the number of visits to [7]
+__device__ long long g_bfs_trace[16];
+#define BFS_MARK(k) do { if (t == 0) { const long long now_ = (long long)wall_clock64(); \
+    if ((k) > 0) { atomicMax((unsigned long long*)&g_bfs_trace[k], (unsigned long long)(now_ - mark_)); atomicAdd((unsigned long long*)&g_bfs_trace[8 + (k)], (unsigned long long)(now_ - mark_)); } \
+    else atomicAdd((unsigned long long*)&g_bfs_trace[7], 1ull); \
+    mark_ = now_; } } while (0)
+#else
+#define BFS_MARK(k) do { } while (0)
+#endif
+
+extern "C" __global__ void __launch_bounds__(64)
+k_bfs_brick_wave(int* __restrict__ dist, int nbx, int nby, int nbz,
                  const int* __restrict__ list_in, const int* __restrict__ counts_in, int* __restrict__ list_next,
                  int* __restrict__ counts_next, int* __restrict__ counts_after, int shard_cap,
-                 int* __restrict__ queued_mine, int* __restrict__ queued_next)
+                 int* __restrict__ queued_mine, int* __restrict__ queued_next, int* __restrict__ queue_size_out, int tag_word, int tag_mask)
 {
-    // The pass builds the next pass's brick list itself: a neighbour brick is claimed with an atomic exchange on its
-    // "queued for the next pass" word and appended by the claimer (no flag sweep, no compaction kernel: 40 launches
-    // fewer per BFS at 256^3).  Two queued-arrays alternate: a brick clears its own word of the array it was queued in,
-    // so that array is clean again when it next serves as "next".  Three counter sets rotate (in / next / the one
-    // zeroed for the pass after).
     constexpr int TL = SMPLX_BRICK_TILE, TP = SMPLX_BRICK_TILE * SMPLX_BRICK_TILE;
     __shared__ unsigned int tile[TL * TL * TL];
     int pre[SMPLX_BFS_SHARDS + 1];
@@ -2330,42 +2382,59 @@ k_bfs_brick_wave(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nb
     const int n = pre[SMPLX_BFS_SHARDS];
     const int t = threadIdx.x;
     if (blockIdx.x == 0 && t < SMPLX_BFS_SHARDS) counts_after[32 * t] = 0;
+    if (blockIdx.x == 0 && t == 0 && queue_size_out) *queue_size_out = n;   // the host sizes the next goal's launches by it
     const int tx = t & 7, ty = t >> 3;
-    const size_t dim_xy = (size_t)dim_x * dim_y;
+#ifdef SMPLX_BFS_TRACE
+    long long mark_ = 0;
+#endif
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
         int sh = 0;
 #pragma unroll
         for (int k = 1; k < SMPLX_BFS_SHARDS; ++k) sh += it >= pre[k] ? 1 : 0;
+        BFS_MARK(0);
         const int b = list_in[(size_t)sh * shard_cap + (it - pre[sh])];
         const int bxx = b % nbx, byy = (b / nbx) % nby, bzz = b / (nbx * nby);
-        const int ox = bxx * SMPLX_BRICK, oy = byy * SMPLX_BRICK, oz = bzz * SMPLX_BRICK;
         if (t == 0) queued_mine[b] = 0;
+        BFS_MARK(1);
         {
-            // 1000 cells by 64 lanes: all 16 loads of a lane in flight before the first store (a rolled loop would put 16
-            // memory round trips end to end: that alone was 15 of the 25 us a lone brick took)
+            // 1000 tile cells by 64 lanes: all 16 loads of a lane in flight before the first store.  The 512 cells of the
+            // brick are one run of its record; a halo cell comes from the neighbour's face copy whose fastest index is the
+            // coordinate that varies along that piece of halo (rows of 8 contiguous ints), a z-parallel edge from the edge copies
             constexpr int NL = (TL * TL * TL + 63) / 64;
+            // every tile cell's source from the table, all loads of a lane in flight together -- without a branch around them:
+            // a load inside a branch is waited for before the branches rejoin, sixteen memory round trips end to end
             int raw[NL];
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
                 const int i = t + 64 * k;
-                const int lx = i % TL, ly = (i / TL) % TL, lz = i / TP;
-                const int px = ox + lx, py = oy + ly, pz = oz + lz;
-                raw[k] = 0x7FFFFFFF;
-                if (i < TL * TL * TL && px < dim_x && py < dim_y && pz < dim_z) raw[k] = dist[(size_t)pz * dim_xy + (size_t)py * dim_x + px];
+                const unsigned int e = c_bfs_tables.src[i < TL * TL * TL ? i : 0];
+                const int qx = bxx + (int)((e >> 10) & 3u) - 1, qy = byy + (int)((e >> 12) & 3u) - 1, qz = bzz + (int)((e >> 14) & 3u) - 1;
+                const bool ok = i < TL * TL * TL && !(qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz);
+                raw[k] = ok ? ((qz * nby + qy) * nbx + qx) * SMPLX_BFS_REC + (int)(e & 1023u) : -1;      // (int: up to 2 M bricks)
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int a = raw[k];
+                const int v = dist[a < 0 ? b * SMPLX_BFS_REC : a];
+                raw[k] = a < 0 ? 0x7FFFFFFF : v;
             }
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
                 const int i = t + 64 * k;
                 if (i < TL * TL * TL)
-                    tile[i] = raw[k] == -1 ? SMPLX_BFS_INF : (raw[k] == 0x7FFFFFFF ? SMPLX_BFS_WALLV : (unsigned int)raw[k]);
+                    tile[i] = raw[k] == 0x7FFFFFFF ? SMPLX_BFS_WALLV : (((raw[k] ^ tag_word) & tag_mask) != 0 || raw[k] == -1 ? SMPLX_BFS_INF : (unsigned int)(raw[k] & ~tag_mask));
             }
         }
         __syncthreads();
+        BFS_MARK(2);
         const int col = (ty + 1) * TL + (tx + 1);   // this lane's column in a tile plane
+        const bool x_lo = tx == 0, x_hi = tx == SMPLX_BRICK - 1, y_lo = ty == 0, y_hi = ty == SMPLX_BRICK - 1;
+        const int xh = x_lo ? 0 : TL - 1, yh = y_lo ? 0 : TL - 1;    // the halo column / row beside a boundary lane
         unsigned int v[SMPLX_BRICK], before[SMPLX_BRICK];
 #pragma unroll
         for (int z = 0; z < SMPLX_BRICK; ++z) { v[z] = tile[(z + 1) * TP + col]; before[z] = v[z]; }
-        // in-plane 3x3 minima of the two halo planes: constant
+        // in-plane 3x3 minima of the two halo planes, and the least halo cell among the in-plane neighbours of every level of
+        // a boundary lane's column: the halo does not change during the visit, so these are read once
         unsigned int p_lo = SMPLX_BFS_WALLV, p_hi = SMPLX_BFS_WALLV;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
@@ -2375,66 +2444,128 @@ k_bfs_brick_wave(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nb
                 p_lo = a < p_lo ? a : p_lo;
                 p_hi = c < p_hi ? c : p_hi;
             }
-        // (the in-plane neighbours by wave shuffles instead of the LDS tile -- x: one lane, y: eight lanes, halo values
-        // in registers, no LDS traffic or barrier in the loop -- was built and measured: 32 ds_bpermute per sweep are
-        // slower than 64 plain LDS reads, 1.69 vs 1.58 ms at 256^3)
+        unsigned int halo_min[SMPLX_BRICK];
+#pragma unroll
+        for (int z = 0; z < SMPLX_BRICK; ++z) halo_min[z] = SMPLX_BFS_WALLV;
+        if (x_lo || x_hi) {
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z)
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) halo_min[z] = bfs_min(halo_min[z], tile[(z + 1) * TP + (ty + 1 + dy) * TL + xh]);
+        }
+        if (y_lo || y_hi) {
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) halo_min[z] = bfs_min(halo_min[z], tile[(z + 1) * TP + yh * TL + (tx + 1 + dx)]);
+        }
+        // The sweeps run in registers: the in-plane neighbours of a column are the columns of lanes t -+ 1 (DPP row shifts) and
+        // t -+ 8 (ds_bpermute), 3x3 = a row window then a window of row windows.  (Through the LDS tile -- 64 reads, 8 writes and
+        // two barriers a sweep -- a sweep took 1.2 us and the nine or so of a brick the front crosses half its visit.)
+        const BfsLanes W = {!x_lo, !x_hi, !y_lo, !y_hi, ((t - 8) & 63) << 2, ((t + 8) & 63) << 2};
+        bool is_wall[SMPLX_BRICK];
+#pragma unroll
+        for (int z = 0; z < SMPLX_BRICK; ++z) is_wall[z] = v[z] == SMPLX_BFS_WALLV;
         while (true) {
-            // the in-plane minimum of every level of the column (own cell included), from the tile as the lanes left it
-            unsigned int pm[SMPLX_BRICK];
+            // 3x3 in-plane minimum of every level (own cell included): all row windows, then all the shifts of them in flight
+            // together, then the halo's share
+            unsigned int pm[SMPLX_BRICK], up[SMPLX_BRICK], down[SMPLX_BRICK], start[SMPLX_BRICK];
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z) { start[z] = v[z]; pm[z] = bfs_window_x(W, v[z]); }
 #pragma unroll
             for (int z = 0; z < SMPLX_BRICK; ++z) {
-                unsigned int m = v[z];
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (dx == 0 && dy == 0) continue;
-                        const unsigned int nv = tile[(z + 1) * TP + col + dy * TL + dx];
-                        m = nv < m ? nv : m;   // walls (0xFFFFFFFF) and undiscovered cells never win
-                    }
-                pm[z] = m;
+                up[z] = (unsigned int)__builtin_amdgcn_ds_bpermute(W.up_addr, (int)pm[z]);
+                down[z] = (unsigned int)__builtin_amdgcn_ds_bpermute(W.down_addr, (int)pm[z]);
             }
-            // relax the column in place, upwards then downwards: a cell takes 1 + the least of the three plane minima
-            bool changed = false;
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z)
+                pm[z] = bfs_min(bfs_min(pm[z], halo_min[z]), bfs_min(W.has_up ? up[z] : SMPLX_BFS_WALLV, W.has_down ? down[z] : SMPLX_BFS_WALLV));
+            // relax the column in place, upwards then downwards: a cell takes 1 + the least of the three plane minima.  No
+            // branches (fifteen divergent ones per sweep were most of its time): an undiscovered or wall minimum + 1 stays
+            // above every cell value, a wall keeps its own value by a select
 #pragma unroll
             for (int z = 0; z < SMPLX_BRICK; ++z) {
-                if (v[z] == SMPLX_BFS_WALLV) continue;
                 const unsigned int lo = z == 0 ? p_lo : pm[z - 1], hi = z == SMPLX_BRICK - 1 ? p_hi : pm[z + 1];
-                unsigned int m = lo < hi ? lo : hi;
-                m = pm[z] < m ? pm[z] : m;
-                if (m < SMPLX_BFS_INF && m + 1 < v[z]) { v[z] = m + 1; pm[z] = v[z] < pm[z] ? v[z] : pm[z]; changed = true; }
+                const unsigned int nv = bfs_min(v[z], bfs_min(bfs_min(lo, hi), pm[z]) + 1u);
+                v[z] = is_wall[z] ? v[z] : nv;
+                pm[z] = bfs_min(pm[z], v[z]);
             }
 #pragma unroll
             for (int z = SMPLX_BRICK - 2; z >= 0; --z) {
-                if (v[z] == SMPLX_BFS_WALLV) continue;
-                const unsigned int hi = pm[z + 1];
-                if (hi < SMPLX_BFS_INF && hi + 1 < v[z]) { v[z] = hi + 1; pm[z] = v[z] < pm[z] ? v[z] : pm[z]; changed = true; }
+                const unsigned int nv = bfs_min(v[z], pm[z + 1] + 1u);
+                v[z] = is_wall[z] ? v[z] : nv;
+                pm[z] = bfs_min(pm[z], v[z]);
             }
-            if (!__syncthreads_or(changed ? 1 : 0)) break;   // one-wave block: the barrier only orders the LDS traffic
+            unsigned int diff = 0;
 #pragma unroll
-            for (int z = 0; z < SMPLX_BRICK; ++z) tile[(z + 1) * TP + col] = v[z];
-            __syncthreads();
+            for (int z = 0; z < SMPLX_BRICK; ++z) diff |= start[z] ^ v[z];
+            if (__ballot(diff != 0u) == 0ull) break;
         }
-        // write back what improved; the neighbour bricks that see an improved cell in their halo are flagged once per
-        // DIRECTION (a 27-bit mask per lane, OR-ed across the wave, one store per set bit) instead of once per cell
-        unsigned int xy = 0;   // (dy + 1) * 3 + (dx + 1) of the in-plane directions this lane's column borders on
-        {
-            const int sx0 = tx == 0 ? -1 : 0, sx1 = tx == SMPLX_BRICK - 1 ? 1 : 0;
-            const int sy0 = ty == 0 ? -1 : 0, sy1 = ty == SMPLX_BRICK - 1 ? 1 : 0;
-            for (int dy = sy0; dy <= sy1; ++dy)
-                for (int dx = sx0; dx <= sx1; ++dx) xy |= 1u << ((dy + 1) * 3 + (dx + 1));
-        }
-        unsigned int mask = 0;
+        BFS_MARK(3);
+        // ---- what improved goes back at once, with its face and edge copies (stores are not waited for) ----
+        int* rec = dist + (size_t)b * SMPLX_BFS_REC;
+        bool improved = false;
 #pragma unroll
         for (int z = 0; z < SMPLX_BRICK; ++z) {
-            if (v[z] < before[z]) {
-                const int px = ox + tx + 1, py = oy + ty + 1, pz = oz + z + 1;
-                dist[(size_t)pz * dim_xy + (size_t)py * dim_x + px] = (int)v[z];
-                mask |= xy << 9;
-                if (z == 0) mask |= xy;
-                if (z == SMPLX_BRICK - 1) mask |= xy << 18;
+            if (!(v[z] < before[z])) continue;
+            improved = true;
+            const int val = (int)v[z] | tag_word;
+            rec[(z << 6) + (ty << 3) + tx] = val;
+            if (x_lo) rec[SMPLX_BFS_FACES + 0 * 64 + z * 8 + ty] = val;
+            if (x_hi) rec[SMPLX_BFS_FACES + 1 * 64 + z * 8 + ty] = val;
+            if (y_lo) rec[SMPLX_BFS_FACES + 2 * 64 + z * 8 + tx] = val;
+            if (y_hi) rec[SMPLX_BFS_FACES + 3 * 64 + z * 8 + tx] = val;
+            if (z == 0) rec[SMPLX_BFS_FACES + 4 * 64 + ty * 8 + tx] = val;
+            if (z == SMPLX_BRICK - 1) rec[SMPLX_BFS_FACES + 5 * 64 + ty * 8 + tx] = val;
+            if ((x_lo || x_hi) && (y_lo || y_hi)) rec[SMPLX_BFS_EDGES + ((y_hi ? 2 : 0) + (x_hi ? 1 : 0)) * 8 + z] = val;
+        }
+        // ---- Which neighbour bricks have to look again: only one that CAN improve -- a cell c' of it (this brick's halo holds
+        // its value h as of the load; it can only have become smaller since) next to a cell c of this brick with h > d(c) + 1.
+        // (Queueing every neighbour that merely SEES a changed cell made the front revisit the bricks behind and beside it: 2.4
+        // visits per brick, most of them a load, one sweep and nothing to write.)  A cell c that did not change in this visit
+        // cannot pass the test against a current h (the neighbour was queued when c got its value and has read it since), so
+        // "changed" need not be tracked.  A halo cell's neighbours in this brick are a window of the brick's boundary layer
+        // -- 3x3 for a face, 3 for an edge, 1 for a corner -- so the test is h against the window minimum, the windows built
+        // from the columns by the same lane shifts as the sweeps; the halo values come from the tile (they are as loaded).
+        // One bit per direction (oz * 9 + oy * 3 + ox, o = 0 / 1 / 2).
+        BFS_MARK(4);
+        unsigned int mask = 0;
+        if (__ballot(improved) != 0ull) {
+            auto can_improve = [](unsigned int h, unsigned int w) { return h != SMPLX_BFS_WALLV && w < SMPLX_BFS_INF && h > w + 1u; };
+            const int ox = x_lo ? 0 : 2, oy = y_lo ? 0 : 2;
+            const bool on_x = x_lo || x_hi, on_y = y_lo || y_hi;
+            unsigned int zw[SMPLX_BRICK];      // window along the column
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z) {
+                zw[z] = v[z];
+                if (z > 0) zw[z] = bfs_min(zw[z], v[z - 1]);
+                if (z < SMPLX_BRICK - 1) zw[z] = bfs_min(zw[z], v[z + 1]);
+            }
+            bool fx = false, fy = false, exy = false;
+#pragma unroll
+            for (int z = 0; z < SMPLX_BRICK; ++z) {
+                const unsigned int yz = bfs_window_y(W, zw[z]), xz = bfs_window_x(W, zw[z]);   // (every lane takes part in the shifts)
+                const unsigned int hx = tile[(z + 1) * TP + (ty + 1) * TL + xh], hy = tile[(z + 1) * TP + yh * TL + (tx + 1)];
+                const unsigned int hxy = tile[(z + 1) * TP + yh * TL + xh];
+                fx = fx || can_improve(hx, yz);
+                fy = fy || can_improve(hy, xz);
+                exy = exy || can_improve(hxy, zw[z]);
+            }
+            if (on_x && fx) mask |= 1u << (1 * 9 + 1 * 3 + ox);
+            if (on_y && fy) mask |= 1u << (1 * 9 + oy * 3 + 1);
+            if (on_x && on_y && exy) mask |= 1u << (1 * 9 + oy * 3 + ox);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const unsigned int vz = side == 0 ? v[0] : v[SMPLX_BRICK - 1];
+                const int zs = side == 0 ? 0 : TL - 1, oz = side == 0 ? 0 : 2;
+                const unsigned int xw = bfs_window_x(W, vz), yw = bfs_window_y(W, vz), xy = bfs_window_y(W, xw);
+                if (can_improve(tile[zs * TP + col], xy)) mask |= 1u << (oz * 9 + 1 * 3 + 1);
+                if (on_x && can_improve(tile[zs * TP + (ty + 1) * TL + xh], yw)) mask |= 1u << (oz * 9 + 1 * 3 + ox);
+                if (on_y && can_improve(tile[zs * TP + yh * TL + (tx + 1)], xw)) mask |= 1u << (oz * 9 + oy * 3 + 1);
+                if (on_x && on_y && can_improve(tile[zs * TP + yh * TL + xh], vz)) mask |= 1u << (oz * 9 + oy * 3 + ox);
             }
         }
+        BFS_MARK(5);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mask |= (unsigned int)__shfl_xor((int)mask, off);
         int claimed = -1;
@@ -2456,140 +2587,8 @@ k_bfs_brick_wave(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nb
                 if (pos < shard_cap) list_next[(size_t)shard * shard_cap + pos] = claimed;
             }
         }
+        BFS_MARK(6);
         __syncthreads();   // the tile is reused by the block's next brick
-    }
-}
-
-extern "C" __global__ void __launch_bounds__(512)
-k_bfs_brick(int* __restrict__ dist, int dim_x, int dim_y, int dim_z, int nbx, int nby, int nbz,
-            const int* __restrict__ list_in, const int* __restrict__ counts_in, int* __restrict__ counts_next, int shard_cap,
-            unsigned char* __restrict__ flags)
-{
-    __shared__ unsigned int tile[SMPLX_BRICK_TILE * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE];
-    // minimum over the 3x3 in-plane neighbourhood (centre included) of every interior (x, y), per tile plane: the 26
-    // neighbours of a cell are three such minima -- 8 + 2 LDS reads per cell and sweep instead of 26
-    __shared__ unsigned int plane[SMPLX_BRICK_TILE][SMPLX_BRICK][SMPLX_BRICK];
-    int pre[SMPLX_BFS_SHARDS + 1];
-    pre[0] = 0;
-#pragma unroll
-    for (int k = 0; k < SMPLX_BFS_SHARDS; ++k) pre[k + 1] = pre[k] + counts_in[32 * k];
-    const int n = pre[SMPLX_BFS_SHARDS];
-    const int t = threadIdx.x;
-    if (blockIdx.x == 0 && t < SMPLX_BFS_SHARDS) counts_next[32 * t] = 0;   // the list k_bfs_compact fills after this pass
-    const int tx = t & 7, ty = (t >> 3) & 7, tz = t >> 6;
-    const size_t dim_xy = (size_t)dim_x * dim_y;
-    for (int it = blockIdx.x; it < n; it += gridDim.x) {   // uniform per block
-        int sh = 0;
-#pragma unroll
-        for (int k = 1; k < SMPLX_BFS_SHARDS; ++k) sh += it >= pre[k] ? 1 : 0;
-        const int b = list_in[(size_t)sh * shard_cap + (it - pre[sh])];
-        const int bxx = b % nbx, byy = (b / nbx) % nby, bzz = b / (nbx * nby);
-        // padded coordinates of the tile's corner: interior cell c sits at padded c + 1, the brick's first interior
-        // cell is 8 * brick, so tile cell l (0..9) is padded 8 * brick + l
-        const int ox = bxx * SMPLX_BRICK, oy = byy * SMPLX_BRICK, oz = bzz * SMPLX_BRICK;
-        for (int i = t; i < SMPLX_BRICK_TILE * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE; i += 512) {
-            const int lx = i % SMPLX_BRICK_TILE, ly = (i / SMPLX_BRICK_TILE) % SMPLX_BRICK_TILE, lz = i / (SMPLX_BRICK_TILE * SMPLX_BRICK_TILE);
-            const int px = ox + lx, py = oy + ly, pz = oz + lz;
-            unsigned int v = SMPLX_BFS_WALLV;
-            if (px < dim_x && py < dim_y && pz < dim_z) {
-                const int raw = dist[(size_t)pz * dim_xy + (size_t)py * dim_x + px];
-                v = raw == -1 ? SMPLX_BFS_INF : (raw == 0x7FFFFFFF ? SMPLX_BFS_WALLV : (unsigned int)raw);
-            }
-            tile[i] = v;
-        }
-        __syncthreads();
-        const int me = (tz + 1) * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE + (ty + 1) * SMPLX_BRICK_TILE + (tx + 1);
-        const unsigned int before = tile[me];
-        unsigned int v = before;
-        // the two halo planes (z = -1 and z = 8 of the brick) never change during the sweeps: their in-plane minima once
-        if (tz == 0 || tz == SMPLX_BRICK - 1) {
-            const int lz = tz == 0 ? 0 : SMPLX_BRICK_TILE - 1;
-            const int c = lz * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE + (ty + 1) * SMPLX_BRICK_TILE + (tx + 1);
-            unsigned int m = SMPLX_BFS_WALLV;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const unsigned int nv = tile[c + dy * SMPLX_BRICK_TILE + dx];
-                    m = nv < m ? nv : m;
-                }
-            plane[lz][ty][tx] = m;
-        }
-        int changed;
-        do {
-            changed = 0;
-            // in-plane minimum of this cell's own plane (the cell itself included: it can never improve on itself)
-            unsigned int p = v;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dx == 0 && dy == 0) continue;
-                    const unsigned int nv = tile[me + dy * SMPLX_BRICK_TILE + dx];
-                    p = nv < p ? nv : p;     // walls (0xFFFFFFFF) and undiscovered cells never win
-                }
-            plane[tz + 1][ty][tx] = p;
-            __syncthreads();
-            if (v != SMPLX_BFS_WALLV) {
-                const unsigned int a = plane[tz][ty][tx], b = plane[tz + 2][ty][tx];
-                unsigned int m = a < b ? a : b;
-                m = p < m ? p : m;
-                if (m < SMPLX_BFS_INF && m + 1 < v) { v = m + 1; tile[me] = v; changed = 1; }
-            }
-        } while (__syncthreads_or(changed));
-        if (v < before) {
-            const int px = ox + tx + 1, py = oy + ty + 1, pz = oz + tz + 1;
-            dist[(size_t)pz * dim_xy + (size_t)py * dim_x + px] = (int)v;
-            // the neighbour bricks that see this cell in their halo
-            const int sx0 = tx == 0 ? -1 : 0, sx1 = tx == SMPLX_BRICK - 1 ? 1 : 0;
-            const int sy0 = ty == 0 ? -1 : 0, sy1 = ty == SMPLX_BRICK - 1 ? 1 : 0;
-            const int sz0 = tz == 0 ? -1 : 0, sz1 = tz == SMPLX_BRICK - 1 ? 1 : 0;
-            for (int dz = sz0; dz <= sz1; ++dz)
-                for (int dy = sy0; dy <= sy1; ++dy)
-                    for (int dx = sx0; dx <= sx1; ++dx) {
-                        if (dx == 0 && dy == 0 && dz == 0) continue;
-                        const int qx = bxx + dx, qy = byy + dy, qz = bzz + dz;
-                        if (qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz) continue;
-                        flags[((size_t)qz * nby + qy) * nbx + qx] = 1;
-                    }
-        }
-        __syncthreads();   // the tile is reused by the block's next brick
-    }
-}
-
-// the flagged bricks become the next pass's list: one flag per lane, ballot, ONE atomicAdd per wave on the wave's shard
-extern "C" __global__ void __launch_bounds__(256)
-k_bfs_compact(unsigned char* __restrict__ flags, int nbricks, int* __restrict__ list_out, int* __restrict__ counts_out, int shard_cap)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool on = b < nbricks && flags[b] != 0;
-    if (on) flags[b] = 0;
-    const unsigned long long m = __ballot(on);
-    if (m == 0) return;
-    const int shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) % SMPLX_BFS_SHARDS;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&counts_out[32 * shard], __popcll(m));
-    base = __shfl(base, 0);
-    if (on) {
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < shard_cap) list_out[(size_t)shard * shard_cap + pos] = b;
-    }
-}
-
-extern "C" __global__ void __launch_bounds__(64)
-k_bfs_brick_seed(int* __restrict__ dist, size_t origin, int brick, int* __restrict__ list0, int* __restrict__ counts)
-{
-    // counts: 2 lists x SMPLX_BFS_SHARDS counters, 32 ints apart
-    if (blockIdx.x == 0) {
-        const int t = threadIdx.x;
-        if (t < 2 * SMPLX_BFS_SHARDS) counts[32 * t] = 0;
-        __syncthreads();
-        if (t == 0) {
-            dist[origin] = 0;      // overwrites a wall at the goal cell, as bfs3d.cpp:178 does
-            list0[0] = brick;      // sub-list 0 of list 0
-            counts[0] = 1;
-        }
     }
 }
 

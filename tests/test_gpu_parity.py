@@ -49,6 +49,31 @@ def test_goal_pose_and_bfs_grid(ctx):
     assert np.array_equal(o.bfs_grid(), s.bfs_grid())
 
 
+def test_bfs_grid_over_ten_goals_in_one_space(small_cfg):
+    """The distances carry the tag of the run that wrote them (device_types.h SmplxBfsDev) and the records are reset only
+    when the tags wrap, at the eighth goal: every goal's grid must equal the oracle's all the same, including one whose
+    cell is out of the grid (bfs3d.cpp:169-171: nothing is labelled) right after a labelled one."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    o = Oracle(small_cfg)
+    s = capi.Space.from_config(small_cfg)
+    rng = np.random.default_rng(17)
+    for k in range(10):
+        g = np.array(small_cfg.goal) + rng.uniform(-0.4, 0.4, size=len(small_cfg.goal))
+        o.set_goal_joint(list(g), small_cfg.goal_tol)
+        s.set_goal_joint(list(g), small_cfg.goal_tol)
+        exp = o.bfs_grid()
+        assert np.array_equal(exp, s.bfs_grid()), f"goal {k}"
+        assert ((exp >= 0) & (exp < 0x7FFFFFFF)).sum() > 1000, "the goal cell is free and the BFS spreads"
+        if k == 4:
+            far = [50.0, 50.0, 50.0]
+            o.set_goal_xyz(far, small_cfg.goal_tol)
+            s.set_goal_xyz(far, small_cfg.goal_tol)
+            out = s.bfs_grid()
+            assert np.array_equal(o.bfs_grid(), out), "out-of-grid goal"
+            assert not ((out >= 0) & (out < 0x7FFFFFFF)).any()
+
+
 def test_sphere_positions_bitwise(ctx):
     cfg, o, s = ctx
     Q = _random_states(64, 1)
@@ -339,13 +364,18 @@ def test_dual_arm_expand_batch(dual_ctx):
     assert (got["flags"] & 1).sum() > 50
 
 
-@pytest.mark.parametrize("shared_scene", [True, 3, 1, False])
-def test_interleaved_multi_query_equals_each_query_alone(small_cfg, shared_scene):
-    """smplx_plan_multi: independent queries interleaved on one GPU by one host thread (BASELINE config 4 shape).
-    Every query must come out exactly as it does alone -- and as the oracle computes it."""
+@pytest.mark.parametrize("shared_scene", ["device", True, 3, 1, False])
+def test_interleaved_multi_query_equals_each_query_alone(small_cfg, shared_scene, monkeypatch):
+    """smplx_plan_multi: independent queries side by side on one GPU (BASELINE config 4 shape).  Every query must come
+    out exactly as it does alone -- and as the oracle computes it.  "device": the default, one persistent workgroup per
+    query (the searches themselves are in tests/test_gpu_device_search.py); the other four the host-driven loop
+    (SMPLX_SEARCH=host) with its thread layouts."""
     from oracle_binding import Oracle
     from smpl_amd import capi
     cfg = small_cfg
+    on_device = shared_scene == "device"
+    if not on_device:
+        monkeypatch.setenv("SMPLX_SEARCH", "host")
     cells = [[-49, 7, 21, -14, -8, -12, 16], [-21, 7, 14, -7, 8, -4, 12], [-35, 14, 7, -14, 4, -8, 8], [-42, 10, 14, -10, 0, -8, 12]]
     goals = [[cfg.start[i] + c * DEG for i, c in enumerate(cs)] for cs in cells]
     spaces = []
@@ -361,7 +391,7 @@ def test_interleaved_multi_query_equals_each_query_alone(small_cfg, shared_scene
         spaces.append(sp)
     # shared scene: True -> 2 host threads, 3 -> 3 (asynchronous driver: worker threads + one GPU submitter), 1 -> one
     # thread (sweeps of one cross-query batch); separate scenes: every query its own batches
-    threads = 2 if shared_scene is True else (shared_scene if shared_scene else 1)
+    threads = 1 if on_device else (2 if shared_scene is True else (shared_scene if shared_scene else 1))
     multi, wall = capi.Space.plan_multi(spaces, 5.0, 1.0, 1.0, True, True, 4000, 2500, host_threads=threads)
     assert wall > 0 and len(multi) == 4
     for g, m in zip(goals, multi):
@@ -373,6 +403,9 @@ def test_interleaved_multi_query_equals_each_query_alone(small_cfg, shared_scene
         assert e["ok"] == m["solved"] and e["cost"] == m["cost"] and e["expansions"] == m["expansions"]
         assert np.array_equal(e["expansion_log"], m["expansion_log"])
         assert np.array_equal(e["path"], m["path"])
+    if on_device:
+        assert spaces[0].search_counters()["searches"] > 0
+        return
     assert sum(m["gpu_batches"] for m in multi) > 4
     if shared_scene:
         # host_threads = 2: worker threads own the searches, ONE submitter thread issues the cross-query batches

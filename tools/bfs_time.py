@@ -1,4 +1,4 @@
-"""GPU probe: BFS time per goal at a BASELINE grid size (brick formulation vs SMPLX_BFS=levels).
+"""GPU probe: BFS time per goal at a BASELINE grid size (brick-major records, one wave per brick).
 Usage: python tools/bfs_time.py [256|512]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,4 +16,4 @@ t = time.perf_counter()
 for g in goals:
     s.set_goal_joint(g, cfg.goal_tol)
 dt = (time.perf_counter() - t) / len(goals)
-print(f"{os.environ.get('SMPLX_BFS', 'bricks')}: grid {n}^3 set_goal (FK + upload + BFS) {dt * 1e3:.3f} ms per goal, passes/levels {s.bfs_levels()}")
+print(f"grid {n}^3 set_goal (FK + upload + BFS) {dt * 1e3:.3f} ms per goal, passes/levels {s.bfs_levels()}")
