@@ -2223,44 +2223,34 @@ __device__ __forceinline__ void bfs_record_store_cell(int* __restrict__ rec, int
     if ((lx == 0 || lx == 7) && (ly == 0 || ly == 7)) rec[SMPLX_BFS_EDGES + (((ly == 7) ? 2 : 0) + ((lx == 7) ? 1 : 0)) * 8 + lz] = v;
 }
 
-// Where the cells of a brick's 10x10x10 tile come from, and where the slots of its record sit in the tile: functions of the
-// position alone, so they are tables (the index arithmetic -- divisions by 10, a five-way case analysis -- was a fifth of a
-// lone brick's visit).  src[i] = offset in the source record | (dx + 1) << 10 | (dy + 1) << 12 | (dz + 1) << 14, (dx, dy, dz)
-// the neighbour brick the cell belongs to.  A halo cell comes from the neighbour's face copy whose fastest index is the
-// coordinate that varies along that piece of halo (rows of 8 contiguous ints), a z-parallel edge from the edge copies.
-struct BfsTileTables { unsigned short src[SMPLX_BRICK_TILE * SMPLX_BRICK_TILE * SMPLX_BRICK_TILE]; unsigned short slot_tile[SMPLX_BFS_USED]; };
-constexpr BfsTileTables bfs_make_tables()
+// The halo of a brick beyond its six faces: 12 edges of 8 cells and 8 corners, piece e < 104.  Where piece e comes from (the
+// neighbour brick (ddx, ddy, ddz), the slot of that brick's record) and where it sits in the 10x10x10 tile: a z-parallel
+// edge from the neighbour's edge copies, an x- or y-parallel one from the face copy whose fastest index runs along it, a
+// corner from an edge copy.  Functions of e alone: a lane works them out once per launch.
+__device__ __forceinline__ void bfs_edge_piece(int e, int& ddx, int& ddy, int& ddz, int& src, int& pos)
 {
-    BfsTileTables T{};
-    constexpr int TL = SMPLX_BRICK_TILE, TP = SMPLX_BRICK_TILE * SMPLX_BRICK_TILE;
-    for (int i = 0; i < TL * TL * TL; ++i) {
-        const int hx = i % TL, hy = (i / TL) % TL, hz = i / TP;
-        const int dx = hx == 0 ? -1 : (hx == TL - 1 ? 1 : 0), dy = hy == 0 ? -1 : (hy == TL - 1 ? 1 : 0), dz = hz == 0 ? -1 : (hz == TL - 1 ? 1 : 0);
-        const int lx = hx - 1 - 8 * dx, ly = hy - 1 - 8 * dy, lz = hz - 1 - 8 * dz;   // the neighbour's own cell
-        int off = SMPLX_BFS_FACES + (lz == 0 ? 4 : 5) * 64 + ly * 8 + lx;             // the z faces and the corners
-        if (dx != 0 && dy == 0) off = SMPLX_BFS_FACES + (lx == 0 ? 0 : 1) * 64 + lz * 8 + ly;      // y varies
-        if (dy != 0 && dx == 0) off = SMPLX_BFS_FACES + (ly == 0 ? 2 : 3) * 64 + lz * 8 + lx;      // x varies (a y face, or an x-parallel edge)
-        if (dx != 0 && dy != 0 && dz == 0) off = SMPLX_BFS_EDGES + (((ly == 7) ? 2 : 0) + ((lx == 7) ? 1 : 0)) * 8 + lz;
-        if (dx == 0 && dy == 0 && dz == 0) off = (lz << 6) + (ly << 3) + lx;
-        T.src[i] = (unsigned short)(off | ((dx + 1) << 10) | ((dy + 1) << 12) | ((dz + 1) << 14));
+    constexpr int TL = SMPLX_BRICK_TILE, TP = SMPLX_BRICK_TILE * SMPLX_BRICK_TILE, HI = SMPLX_BRICK_TILE - 1;
+    const int i = e & 7, k = (e >> 3) & 3, g = e >> 5;
+    const int s0 = k & 1, s1 = k >> 1;          // 0: the low side (neighbour at -1, its cell 7), 1: the high side
+    if (g == 0) {            // z runs; (x, y) sides s0, s1
+        ddx = s0 ? 1 : -1; ddy = s1 ? 1 : -1; ddz = 0;
+        src = SMPLX_BFS_EDGES + ((s1 ? 0 : 2) + (s0 ? 0 : 1)) * 8 + i;
+        pos = (i + 1) * TP + (s1 ? HI : 0) * TL + (s0 ? HI : 0);
+    } else if (g == 1) {     // x runs; (y, z) sides s0, s1: the neighbour's y face copy
+        ddx = 0; ddy = s0 ? 1 : -1; ddz = s1 ? 1 : -1;
+        src = SMPLX_BFS_FACES + (s0 ? 2 : 3) * 64 + (s1 ? 0 : 7) * 8 + i;
+        pos = (s1 ? HI : 0) * TP + (s0 ? HI : 0) * TL + (i + 1);
+    } else if (g == 2) {     // y runs; (x, z) sides s0, s1: the neighbour's x face copy
+        ddx = s0 ? 1 : -1; ddy = 0; ddz = s1 ? 1 : -1;
+        src = SMPLX_BFS_FACES + (s0 ? 0 : 1) * 64 + (s1 ? 0 : 7) * 8 + i;
+        pos = (s1 ? HI : 0) * TP + (i + 1) * TL + (s0 ? HI : 0);
+    } else {                 // corners: e = 96 + (cx | cy << 1 | cz << 2)
+        const int cx = i & 1, cy = (i >> 1) & 1, cz = (i >> 2) & 1;
+        ddx = cx ? 1 : -1; ddy = cy ? 1 : -1; ddz = cz ? 1 : -1;
+        src = SMPLX_BFS_EDGES + ((cy ? 0 : 2) + (cx ? 0 : 1)) * 8 + (cz ? 0 : 7);
+        pos = (cz ? HI : 0) * TP + (cy ? HI : 0) * TL + (cx ? HI : 0);
     }
-    for (int s = 0; s < SMPLX_BFS_USED; ++s) {
-        int lx = 0, ly = 0, lz = 0;
-        if (s < SMPLX_BFS_FACES) { lz = s >> 6; ly = (s >> 3) & 7; lx = s & 7; }
-        else if (s < SMPLX_BFS_EDGES) {
-            const int f = (s - SMPLX_BFS_FACES) >> 6, a = ((s - SMPLX_BFS_FACES) >> 3) & 7, c = (s - SMPLX_BFS_FACES) & 7;
-            if (f < 2) { lx = f == 0 ? 0 : 7; lz = a; ly = c; }
-            else if (f < 4) { ly = f == 2 ? 0 : 7; lz = a; lx = c; }
-            else { lz = f == 4 ? 0 : 7; ly = a; lx = c; }
-        } else {
-            const int k = (s - SMPLX_BFS_EDGES) >> 3;
-            lz = (s - SMPLX_BFS_EDGES) & 7; lx = (k & 1) ? 7 : 0; ly = (k & 2) ? 7 : 0;
-        }
-        T.slot_tile[s] = (unsigned short)((lz + 1) * TP + (ly + 1) * TL + (lx + 1));
-    }
-    return T;
 }
-__constant__ BfsTileTables c_bfs_tables = bfs_make_tables();
 
 // walls: BfsHeuristic::syncGridAndBfs (bfs_heuristic.cpp:331-353) in integer form:
 // wall iff squared cell distance <= wall_thr (largest i with res*sqrt(i) <= radius; -1 if none)
@@ -2384,6 +2374,15 @@ k_bfs_brick_wave(int* __restrict__ dist, int nbx, int nby, int nbz,
     if (blockIdx.x == 0 && t < SMPLX_BFS_SHARDS) counts_after[32 * t] = 0;
     if (blockIdx.x == 0 && t == 0 && queue_size_out) *queue_size_out = n;   // the host sizes the next goal's launches by it
     const int tx = t & 7, ty = t >> 3;
+    // the two edge / corner pieces of this lane: pieces t and 64 + t (104 in all)
+    int piece_from[2], piece_pos[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int ddx, ddy, ddz, src, pos;
+        bfs_edge_piece(t + 64 * k < 104 ? t + 64 * k : 0, ddx, ddy, ddz, src, pos);
+        piece_from[k] = (ddx + 1) | ((ddy + 1) << 2) | ((ddz + 1) << 4) | (src << 6);
+        piece_pos[k] = t + 64 * k < 104 ? pos : -1;
+    }
 #ifdef SMPLX_BFS_TRACE
     long long mark_ = 0;
 #endif
@@ -2396,43 +2395,52 @@ k_bfs_brick_wave(int* __restrict__ dist, int nbx, int nby, int nbz,
         const int bxx = b % nbx, byy = (b / nbx) % nby, bzz = b / (nbx * nby);
         if (t == 0) queued_mine[b] = 0;
         BFS_MARK(1);
+        unsigned int v[SMPLX_BRICK], before[SMPLX_BRICK];
         {
-            // 1000 tile cells by 64 lanes: all 16 loads of a lane in flight before the first store.  The 512 cells of the
-            // brick are one run of its record; a halo cell comes from the neighbour's face copy whose fastest index is the
-            // coordinate that varies along that piece of halo (rows of 8 contiguous ints), a z-parallel edge from the edge copies
-            constexpr int NL = (TL * TL * TL + 63) / 64;
-            // every tile cell's source from the table, all loads of a lane in flight together -- without a branch around them:
-            // a load inside a branch is waited for before the branches rejoin, sixteen memory round trips end to end
-            int raw[NL];
+            // Sixteen loads a lane, all in flight before the first is used and none inside a branch (a load in a branch is
+            // waited for before the branches rejoin).  The lane's own column: eight words of the brick's record, 256 bytes
+            // apart -- straight to registers.  The halo goes through the tile: six faces, each one 64-word run of a
+            // neighbour's face copy; the edges and corners, 104 words, as pieces (bfs_edge_piece).  A neighbour beyond the grid
+            // reads as walls.
+            const int own = b * SMPLX_BFS_REC;      // (int: up to 2 M bricks)
+            int raw[SMPLX_BRICK], face[6], piece[2];
 #pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int i = t + 64 * k;
-                const unsigned int e = c_bfs_tables.src[i < TL * TL * TL ? i : 0];
-                const int qx = bxx + (int)((e >> 10) & 3u) - 1, qy = byy + (int)((e >> 12) & 3u) - 1, qz = bzz + (int)((e >> 14) & 3u) - 1;
-                const bool ok = i < TL * TL * TL && !(qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz);
-                raw[k] = ok ? ((qz * nby + qy) * nbx + qx) * SMPLX_BFS_REC + (int)(e & 1023u) : -1;      // (int: up to 2 M bricks)
+            for (int z = 0; z < SMPLX_BRICK; ++z) raw[z] = dist[own + 64 * z + t];
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                const int d = (f & 1) ? 1 : -1;
+                const int qx = bxx + (f < 2 ? d : 0), qy = byy + (f >= 2 && f < 4 ? d : 0), qz = bzz + (f >= 4 ? d : 0);
+                const bool ok = !(qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz);      // (uniform)
+                const int w = dist[ok ? ((qz * nby + qy) * nbx + qx) * SMPLX_BFS_REC + SMPLX_BFS_FACES + (f ^ 1) * 64 + t : own];
+                face[f] = ok ? w : 0x7FFFFFFF;
             }
 #pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int a = raw[k];
-                const int v = dist[a < 0 ? b * SMPLX_BFS_REC : a];
-                raw[k] = a < 0 ? 0x7FFFFFFF : v;
+            for (int k = 0; k < 2; ++k) {
+                const int qx = bxx + ((piece_from[k] & 3) - 1), qy = byy + (((piece_from[k] >> 2) & 3) - 1), qz = bzz + (((piece_from[k] >> 4) & 3) - 1);
+                const bool ok = !(qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz);
+                const int w = dist[ok ? ((qz * nby + qy) * nbx + qx) * SMPLX_BFS_REC + (piece_from[k] >> 6) : own];
+                piece[k] = ok ? w : 0x7FFFFFFF;
             }
+            auto decode = [&](int w) {
+                return w == 0x7FFFFFFF ? SMPLX_BFS_WALLV : ((((w ^ tag_word) & tag_mask) != 0 || w == -1) ? SMPLX_BFS_INF : (unsigned int)(w & ~tag_mask));
+            };
 #pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int i = t + 64 * k;
-                if (i < TL * TL * TL)
-                    tile[i] = raw[k] == 0x7FFFFFFF ? SMPLX_BFS_WALLV : (((raw[k] ^ tag_word) & tag_mask) != 0 || raw[k] == -1 ? SMPLX_BFS_INF : (unsigned int)(raw[k] & ~tag_mask));
+            for (int z = 0; z < SMPLX_BRICK; ++z) { v[z] = decode(raw[z]); before[z] = v[z]; }
+            const int a8 = t >> 3, c8 = t & 7;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                const int side = (f & 1) ? TL - 1 : 0;
+                const int pos = f < 2 ? (a8 + 1) * TP + (c8 + 1) * TL + side : (f < 4 ? (a8 + 1) * TP + side * TL + (c8 + 1) : side * TP + (a8 + 1) * TL + (c8 + 1));
+                tile[pos] = decode(face[f]);
             }
+            tile[piece_pos[0]] = decode(piece[0]);
+            if (piece_pos[1] >= 0) tile[piece_pos[1]] = decode(piece[1]);
         }
         __syncthreads();
         BFS_MARK(2);
         const int col = (ty + 1) * TL + (tx + 1);   // this lane's column in a tile plane
         const bool x_lo = tx == 0, x_hi = tx == SMPLX_BRICK - 1, y_lo = ty == 0, y_hi = ty == SMPLX_BRICK - 1;
         const int xh = x_lo ? 0 : TL - 1, yh = y_lo ? 0 : TL - 1;    // the halo column / row beside a boundary lane
-        unsigned int v[SMPLX_BRICK], before[SMPLX_BRICK];
-#pragma unroll
-        for (int z = 0; z < SMPLX_BRICK; ++z) { v[z] = tile[(z + 1) * TP + col]; before[z] = v[z]; }
         // in-plane 3x3 minima of the two halo planes, and the least halo cell among the in-plane neighbours of every level of
         // a boundary lane's column: the halo does not change during the visit, so these are read once
         unsigned int p_lo = SMPLX_BFS_WALLV, p_hi = SMPLX_BFS_WALLV;
