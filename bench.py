@@ -349,7 +349,7 @@ def main():
                 k2_traffic = json.load(f)["k_state_valid"]["bytes_per_launch"] if n2 == (1 << 20) and args.grid == 256 else None
         except (OSError, KeyError, ValueError):
             k2_traffic = None
-        k2 = {"kernel": "k_state_valid", "configs": n2, "inputs": "q ~ U[limits], std::mt19937_64 seed 12345 (benchmark_cc.cpp:280-301 scheme)",
+        k2 = {"kernel": "k_state_valid", "configs": n2, "inputs": "q ~ U[limits]: same distribution as benchmark_cc.cpp:280-301, SURVEY-specified engine and seed (std::mt19937_64, 12345); parity against the oracle only",
               "kernel_ms": round(ms, 4), "collision_checks_per_s": round(n2 / (ms * 1e-3), 1), "valid_fraction": round(nvalid / n2, 4),
               "lookups": lk_total, "algorithmic_bytes": int(k2_bytes),
               "roofline": {"bound": "hbm", "achieved": round(k2_bytes / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

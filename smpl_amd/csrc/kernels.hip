@@ -230,6 +230,14 @@ __device__ __forceinline__ void apply_joint(JointPtr jt, double q, double T[12],
     apply_joint_t(kind, o[3], o[7], o[11], q, T, on_root);
 }
 
+#define SMPLX_GLOBAL_AS __attribute__((address_space(1)))
+// A pointer read out of a struct in memory (or out of LDS) is a FLAT address to the compiler: its loads and stores count on
+// the LDS counter as well as on the memory counter, so every wait for an LDS read behind them waits for HBM too, and
+// the other way round.  The buffers of this engine are all device memory: as_global says so.  (The type has to carry it: a
+// cast to address space 1 and back is folded away, and the compiler takes no hint from an assumption.)
+template <class T>
+__device__ __forceinline__ SMPLX_GLOBAL_AS T* as_global(T* p) { return (SMPLX_GLOBAL_AS T*)p; }
+
 // voxel lookup: squared cell distance at a world point, 0 outside the grid
 // (occupancy_grid.h:234 -> distance_map.hpp:281-300, 520-536)
 __device__ __forceinline__ int grid_d2(const SmplxGridDev& g, const double p[3])
@@ -237,9 +245,17 @@ __device__ __forceinline__ int grid_d2(const SmplxGridDev& g, const double p[3])
     const int x = (int)(g.inv_res * (p[0] - g.origin_minus_res[0]) + 0.5) - 1;
     const int y = (int)(g.inv_res * (p[1] - g.origin_minus_res[1]) + 0.5) - 1;
     const int z = (int)(g.inv_res * (p[2] - g.origin_minus_res[2]) + 0.5) - 1;
-    if (x < 0 || y < 0 || z < 0 || x >= g.n[0] || y >= g.n[1] || z >= g.n[2]) return 0;
+    // no branch around the load: a load inside a branch is waited for where the branches rejoin, which put the whole
+    // round trip in front of whatever the caller meant to overlap with it.  Out of the grid: cell 0 is read and dropped.
+    const bool outside = x < 0 || y < 0 || z < 0 || x >= g.n[0] || y >= g.n[1] || z >= g.n[2];
     const size_t brick = ((size_t)(x >> 2) * g.bricks[1] + (y >> 2)) * g.bricks[2] + (z >> 2);
-    return (int)g.d2[brick * 64 + ((x & 3) << 4) + ((y & 3) << 2) + (z & 3)];
+    const size_t cell = brick * 64 + ((x & 3) << 4) + ((y & 3) << 2) + (z & 3);
+    // the pointer comes out of a struct read from memory, so the compiler takes it for a FLAT address: a flat load counts
+    // on the LDS counter as well, and every wait for an LDS read behind it (saved transforms, tree nodes) waited for the
+    // grid gather too.  It is device memory: say so.
+    const SMPLX_GLOBAL_AS unsigned short* d2 = (const SMPLX_GLOBAL_AS unsigned short*)g.d2;
+    const int v = (int)d2[outside ? (size_t)0 : cell];
+    return outside ? 0 : v;
 }
 
 // interpolated value of planning variable v on the edge start -> finish at parameter alpha
@@ -499,10 +515,10 @@ __device__ __forceinline__ void issue_root(const SmplxGridDev& g, ChainState& C,
 
 template <int T_>
 __device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
-                                             ChainState& C, int& lookups)
+                                             const double* Tp, int pd2, int& lookups)
 {
     (void)M;
-    if (!(C.pd2 < CM_ROOT_THR[T_])) return true;
+    if (!(pd2 < CM_ROOT_THR[T_])) return true;
     if constexpr (CM_ROOT_LEFT[T_] < 0) {
         return false;
     } else {
@@ -518,7 +534,7 @@ __device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, con
             const LDS_AS SmplxNode& nd = L.nodes[node];
             double c[3] = {nd.c[0], nd.c[1], nd.c[2]};
             double p[3];
-            xform(C.Tp, c, p);
+            xform(Tp, c, p);
             ++lookups;
 #ifdef ABL_NO_LOOKUP
             const int dd = 60000 + (int)(p[0] * 0.0);
@@ -561,7 +577,7 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         // the lookup issued at the previous tree has had this joint's sincos and products to land behind
         if constexpr (PT >= 0) {
 #ifndef ABL_NO_TREES
-            if (!resolve_root<PT>(M, L, g, C, lookups)) return false;
+            if (!resolve_root<PT>(M, L, g, C.Tp, C.pd2, lookups)) return false;
 #endif
         }
         if constexpr (tree >= 0) {
@@ -583,7 +599,7 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
     } else {
         if constexpr (PT >= 0) {
 #ifndef ABL_NO_TREES
-            return resolve_root<PT>(M, L, g, C, lookups);
+            return resolve_root<PT>(M, L, g, C.Tp, C.pd2, lookups);
 #else
             return true;
 #endif
@@ -921,7 +937,8 @@ __device__ __forceinline__ bool bfs_in_bounds(const SmplxBfsDev& b, const int c[
 __device__ __forceinline__ int bfs_dist(const SmplxBfsDev& b, const int c[3])
 {
     const size_t brick = ((size_t)(c[2] >> 3) * b.nby + (c[1] >> 3)) * b.nbx + (c[0] >> 3);
-    const int v = b.dist[brick * SMPLX_BFS_REC + ((c[2] & 7) << 6) + ((c[1] & 7) << 3) + (c[0] & 7)];
+    const SMPLX_GLOBAL_AS int* dist = (const SMPLX_GLOBAL_AS int*)b.dist;     // (device memory, not a flat address: see grid_d2)
+    const int v = dist[brick * SMPLX_BFS_REC + ((c[2] & 7) << 6) + ((c[1] & 7) << 3) + (c[0] & 7)];
     if (v == 0x7FFFFFFF) return v;
     return ((v ^ b.tag_word) & b.tag_mask) != 0 ? -1 : (v & ~b.tag_mask);     // another run's value: UNDISCOVERED
 }
@@ -971,16 +988,24 @@ __device__ __forceinline__ int var_to_coord(const ModelLds* __restrict__ M, int 
 // Inserts of the same launch may still be running (they ride at the head of the batch's first kernel): a slot whose tag
 // is negative is being filled.  No slot between a coordinate's home and its own slot can have been empty since it was
 // inserted, so meeting an empty or a busy slot first means the coordinate was not in the table before this launch.
+// ConcurrentInserts: inserts may run in other workgroups of the SAME launch (k_small_batch: the extra blocks of
+// table_insert_block).  In the pipeline the inserts ride with the first kernel and the lookups run in the last one, a
+// kernel boundary later, where plain loads do (acquires there cost k_pipe_finish 15 -> 33 us, measured).
+template <bool ConcurrentInserts>
 __device__ __forceinline__ int table_lookup(const SmplxTableDev& T, const int* __restrict__ c, int nv)
 {
     if (!T.slots) return -1;
     unsigned int i = smplx_coord_hash(c, nv) & T.mask;
     while (true) {
-        const int* sl = T.slots + (size_t)i * T.stride;
-        const int tag = __atomic_load_n(&sl[0], __ATOMIC_RELAXED);
-        if (tag <= 0) return -1;
+        const SMPLX_GLOBAL_AS int* sl = as_global(T.slots) + (size_t)i * T.stride;
+        // ConcurrentInserts (k_small_batch): table_insert_item publishes the tag with a release after the coordinates, from
+        // another workgroup; the tag is read with an acquire and the coordinates with loads that bypass this CU's L1, which is
+        // never refreshed by another CU's stores -- a plain load could compare against a stale line (zeros, or half a
+        // coordinate) and return another state's id
+        const int tag = ConcurrentInserts ? __atomic_load_n(&sl[0], __ATOMIC_ACQUIRE) : __atomic_load_n(&sl[0], __ATOMIC_RELAXED);
+        if (tag <= 0) return -1;          // free, or being filled: a miss (the host resolves misses)
         bool same = true;
-        for (int v = 0; v < nv; ++v) same = same && sl[1 + v] == c[v];
+        for (int v = 0; v < nv; ++v) same = same && (ConcurrentInserts ? __atomic_load_n(&sl[1 + v], __ATOMIC_RELAXED) : sl[1 + v]) == c[v];
         if (same) return tag - 1;
         i = (i + 1) & T.mask;
     }
@@ -999,12 +1024,11 @@ __device__ __forceinline__ void table_insert_item(const SmplxSpaceDev* __restric
     for (int v = 0; v < nvars; ++v) c[v] = it[2 + v];   // the items may live in pinned host memory: read them once
     unsigned int k = smplx_coord_hash(c, nvars) & T.mask;
     while (true) {
-        int* sl = T.slots + (size_t)k * T.stride;
+        SMPLX_GLOBAL_AS int* sl = as_global(T.slots) + (size_t)k * T.stride;
         // claim with a negative ("busy") tag, fill, publish: a concurrent lookup never sees a half-written slot as a hit
-        if (atomicCAS(&sl[0], 0, -(id + 1)) == 0) {
-            for (int v = 0; v < nvars; ++v) sl[1 + v] = c[v];
-            __threadfence();
-            __atomic_store_n(&sl[0], id + 1, __ATOMIC_RELAXED);
+        if (atomicCAS((int*)&sl[0], 0, -(id + 1)) == 0) {
+            for (int v = 0; v < nvars; ++v) __atomic_store_n(&sl[1 + v], c[v], __ATOMIC_RELAXED);
+            __atomic_store_n(&sl[0], id + 1, __ATOMIC_RELEASE);
             return;
         }
         k = (k + 1) & T.mask;
@@ -1693,7 +1717,7 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
                 MV_UNROLL
                 for (int v = 0; v < nv; ++v) sc[v] = var_to_coord(M, v, sq[v]);
                 // K5: the table lookup only needs the coordinates; issued here, its probe lands behind the planning-link FK
-                if (out_id) { early_id = table_lookup(Sq->table, sc, nv); have_early = true; }
+                if (out_id) { early_id = table_lookup<false>(Sq->table, sc, nv); have_early = true; }
                 double p[3];
                 planning_fk(M, sq, p);
                 bool is_goal;
@@ -1726,7 +1750,7 @@ k_pipe_finish(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         // K5: getHashEntry on the device copy of the state table (manip_lattice.cpp:1302-1316).  The id is only a
         // hint to the host (it skips its own lookup); ids are still ASSIGNED on the host, in commit order.
         if (out_id) {
-            if (flags & SMPLX_F_VALID) succ_id = have_early ? early_id : table_lookup(Sq->table, out_coord + tid * nv, nv);
+            if (flags & SMPLX_F_VALID) succ_id = have_early ? early_id : table_lookup<false>(Sq->table, out_coord + tid * nv, nv);
             out_id[tid] = succ_id;
         }
     }
@@ -2063,7 +2087,7 @@ k_small_batch(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
         if (flags & SMPLX_F_VALID) {
             MV_UNROLL
             for (int v = 0; v < nv; ++v) out_coord[eid * nv + v] = X.coord[t][v];
-            if (out_id) sid = table_lookup(Sq->table, X.coord[t], nv);   // K5: device copy of the state table (see k_pipe_finish)
+            if (out_id) sid = table_lookup<true>(Sq->table, X.coord[t], nv);   // K5: device copy of the state table (see k_pipe_finish)
         }
         if (out_id) out_id[eid] = sid;
         if (host_flags) {

@@ -55,8 +55,8 @@ __device__ __forceinline__ hent_t hent_make(unsigned int f, int id) { return (he
 
 struct HeapRef {
     LDS_AS hent_t* lds;                    // entries [0, lh)
-    hent_t* hbm;                           // entries [lh, ...)
-    SmplxSState* st;
+    SMPLX_GLOBAL_AS hent_t* hbm;           // entries [lh, ...)
+    SMPLX_GLOBAL_AS SmplxSState* st;
     int lh;
 };
 
@@ -270,19 +270,19 @@ __device__ __forceinline__ void sstate_reinit(SmplxSState& s, int call_number)
 typedef int __attribute__((ext_vector_type(4))) sk_int4;
 
 // write a state's fields back; heap_index only when the caller owns it (it is otherwise kept current by the sifts)
-__device__ __forceinline__ void sstate_store(SmplxSState* dst, const SmplxSState& s, bool with_heap_index)
+__device__ __forceinline__ void sstate_store(SMPLX_GLOBAL_AS SmplxSState* dst, const SmplxSState& s, bool with_heap_index)
 {
     sk_int4 a;
     a.x = (int)s.g; a.y = (int)s.h; a.z = (int)s.f; a.w = (int)s.eg;
-    *reinterpret_cast<sk_int4*>(dst) = a;
+    *(SMPLX_GLOBAL_AS sk_int4*)dst = a;
     dst->bp = s.bp;
     if (with_heap_index) dst->heap_index = s.heap_index;
-    *reinterpret_cast<unsigned int*>(&dst->iteration_closed) = (unsigned int)s.iteration_closed | ((unsigned int)s.call_number << 16);
+    *(SMPLX_GLOBAL_AS unsigned int*)&dst->iteration_closed = (unsigned int)s.iteration_closed | ((unsigned int)s.call_number << 16);
     dst->flags = s.flags;
 }
-__device__ __forceinline__ SmplxSState sstate_load(const SmplxSState* src)
+__device__ __forceinline__ SmplxSState sstate_load(const SMPLX_GLOBAL_AS SmplxSState* src)
 {
-    const sk_int4 a = reinterpret_cast<const sk_int4*>(src)[0], b = reinterpret_cast<const sk_int4*>(src)[1];
+    const sk_int4 a = ((const SMPLX_GLOBAL_AS sk_int4*)src)[0], b = ((const SMPLX_GLOBAL_AS sk_int4*)src)[1];
     SmplxSState s;
     s.g = (unsigned int)a.x; s.h = (unsigned int)a.y; s.f = (unsigned int)a.z; s.eg = (unsigned int)a.w;
     s.bp = b.x; s.heap_index = b.y;
@@ -298,7 +298,7 @@ struct TableProbe { int id; unsigned int free_slot; };
 struct TableProbeLoads { sk_int4 w[4]; unsigned int slot; };
 __device__ __forceinline__ void table_slot_load(const SmplxTableDev& T, unsigned int slot, int nv, sk_int4 w[4])
 {
-    const sk_int4* sl = reinterpret_cast<const sk_int4*>(T.slots + (size_t)slot * T.stride);
+    const SMPLX_GLOBAL_AS sk_int4* sl = (const SMPLX_GLOBAL_AS sk_int4*)(as_global(T.slots) + (size_t)slot * T.stride);
     const int nw = (nv + 1 + 3) / 4;       // 16-byte words that hold the tag and the coordinate (stride is a multiple of 8 ints)
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (k < nw) w[k] = sl[k];
@@ -337,7 +337,7 @@ __device__ __forceinline__ TableProbe table_probe_finish(const SmplxTableDev& T,
 }
 __device__ __forceinline__ void table_store_own(const SmplxTableDev& T, unsigned int slot, const LDS_AS int* c, int nv, int id)
 {
-    int* sl = T.slots + (size_t)slot * T.stride;
+    SMPLX_GLOBAL_AS int* sl = as_global(T.slots) + (size_t)slot * T.stride;
     for (int v = 0; v < nv; ++v) sl[1 + v] = c[v];
     sl[0] = id + 1;
 }
@@ -428,8 +428,8 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                            (unsigned int)((3 * nroot_lds + 12 * Mv.nslots + Mv.nvars) * 8 + SMPLX_STACK_BYTES) * blockDim.x;
         off = (off + 15u) & ~15u;
         H.lds = (LDS_AS hent_t*)((LDS_AS unsigned char*)smem + off);
-        H.hbm = (hent_t*)P->heap;
-        H.st = P->st;
+        H.hbm = (SMPLX_GLOBAL_AS hent_t*)as_global(P->heap);
+        H.st = as_global(P->st);
         H.lh = lh;
     }
     {
@@ -450,7 +450,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 const double eps = W.reorder_eps;
                 for (int i = 1 + t; i <= size; i += blockDim.x) {     // f of every OPEN entry under the new epsilon (arastar.cpp:571-577)
                     const int eid = hent_id(hget(H, i));
-                    SmplxSState* ss = &P->st[eid];
+                    SMPLX_GLOBAL_AS SmplxSState* ss = &as_global(P->st)[eid];
                     const unsigned int f = search_key(eps, ss->g, ss->h);
                     ss->f = f;
                     hput(H, i, hent_make(f, eid));
@@ -483,7 +483,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             R.heap_size = 0; R.n_incons = 0; R.n_log = 0;
             R.call_number = (R.call_number + 1) & 0xFFFF;
             if (R.call_number == 0) R.call_number = 1;
-            SmplxSState ss = sstate_load(&P->st[P->start_id]), gs = sstate_load(&P->st[0]);
+            SmplxSState ss = sstate_load(&as_global(P->st)[P->start_id]), gs = sstate_load(&as_global(P->st)[0]);
             sstate_reinit(ss, R.call_number);
             sstate_reinit(gs, R.call_number);
             R.iteration = 1;
@@ -494,8 +494,8 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             R.goal_f = P->start_id == 0 ? ss.f : gs.f;
             R.heap_size = 1;
             if (lane == 0) {
-                sstate_store(&P->st[P->start_id], ss, true);
-                if (P->start_id != 0) sstate_store(&P->st[0], gs, true);
+                sstate_store(&as_global(P->st)[P->start_id], ss, true);
+                if (P->start_id != 0) sstate_store(&as_global(P->st)[0], gs, true);
                 hset(H, 1, hent_make(ss.f, P->start_id));
             }
             R.num = 0; R.err = 0; R.expand_count = 0; R.expand_count_init = 0; R.dup_pushes = 0;
@@ -567,10 +567,10 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 R.curr_eps -= P->delta_eps;
                 R.curr_eps = R.curr_eps > P->final_eps ? R.curr_eps : P->final_eps;
                 for (int i = 0; i < R.n_incons; ++i) {
-                    const int sid = P->incons[i];
-                    const SmplxSState ss = sstate_load(&P->st[sid]);
+                    const int sid = as_global(P->incons)[i];
+                    const SmplxSState ss = sstate_load(&as_global(P->st)[sid]);
                     if (ss.heap_index != 0) {                       // already in OPEN: the same element twice from now on
-                        if (lane == 0) P->st[sid].flags = ss.flags | 1u;
+                        if (lane == 0) as_global(P->st)[sid].flags = ss.flags | 1u;
                         ++R.dup_pushes;
                     }
                     ++R.heap_size;
@@ -584,7 +584,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     const int size = R.heap_size;
                     for (int i = 1 + t; i <= size; i += blockDim.x) {
                         const int eid = hent_id(hget(H, i));
-                        SmplxSState* ss = &P->st[eid];
+                        SMPLX_GLOBAL_AS SmplxSState* ss = &as_global(P->st)[eid];
                         const unsigned int f = search_key(R.curr_eps, ss->g, ss->h);
                         ss->f = f;
                         hput(H, i, hent_make(f, eid));
@@ -593,7 +593,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     heap_make_block(H, size, R.dup_pushes > 0);
                 }
                 __syncthreads();                                   // B
-                R.goal_f = P->st[0].f;      // (the goal state is re-initialised when a call starts: its f is this call's)
+                R.goal_f = as_global(P->st)[0].f;      // (the goal state is re-initialised when a call starts: its f is this call's)
                 R.phase = 2;
                 SK_TICK(5);
                 continue;
@@ -603,20 +603,20 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             // ---- pop (intrusive_heap.hpp:155-166).  The state popped is very often one the previous relaxation has just
             // stored (another lane of this wave did): those stores have landed before it is read ----
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            const SmplxSState sm = sstate_load(&P->st[m]);           // g, h: in flight together with the loads below
+            const SmplxSState sm = sstate_load(&as_global(P->st)[m]);           // g, h: in flight together with the loads below
             const hent_t last = hget(H, R.heap_size);
-            const int off = P->done_off[m];                          // >= 0: expanded before (a later ARA* iteration)
-            const int dcnt = P->done_cnt[m];
-            if (lane < nv) X.parent[lane] = P->q[(size_t)m * nv + lane];
+            const int off = as_global(P->done_off)[m];                          // >= 0: expanded before (a later ARA* iteration)
+            const int dcnt = as_global(P->done_cnt)[m];
+            if (lane < nv) X.parent[lane] = as_global(P->q)[(size_t)m * nv + lane];
             if (lane < nprims) { X.edge_bad[lane] = 0; X.edge_lk[lane] = 0; }
-            if (lane == 0) { X.state_bad = 0; X.state_lookups = 0; P->st[m].heap_index = 0; }
+            if (lane == 0) { X.state_bad = 0; X.state_lookups = 0; as_global(P->st)[m].heap_index = 0; }
             --R.heap_size;
             if (R.heap_size >= 1) heap_sift_down_wave(H, lane, 1, R.heap_size, last);
             const unsigned int eg = sm.g;
             if (lane == 0) {
-                *reinterpret_cast<unsigned int*>(&P->st[m].iteration_closed) = ((unsigned int)R.iteration & 0xFFFFu) | ((unsigned int)sm.call_number << 16);
-                P->st[m].eg = eg;
-                P->log[R.n_log] = m;
+                *(SMPLX_GLOBAL_AS unsigned int*)&as_global(P->st)[m].iteration_closed = ((unsigned int)R.iteration & 0xFFFFu) | ((unsigned int)sm.call_number << 16);
+                as_global(P->st)[m].eg = eg;
+                as_global(P->log)[R.n_log] = m;
             }
             ++R.n_log;
             SK_TICK(1);
@@ -660,10 +660,10 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         TableProbeLoads ld = table_probe_start(table, nv, hash);
                         expand_book_goal(M, grid, bfs, Sq, X, lane, b);
                         pr = table_probe_finish(table, ld, (const LDS_AS int*)X.coord[lane], nv);
-                        if (pr.id >= 0 && !b.is_goal) ss = sstate_load(&P->st[pr.id]);
+                        if (pr.id >= 0 && !b.is_goal) ss = sstate_load(&as_global(P->st)[pr.id]);
                     }
                 }
-                const SmplxSState goal_ss = sstate_load(&P->st[0]);   // (a goal successor relaxes the goal state)
+                const SmplxSState goal_ss = sstate_load(&as_global(P->st)[0]);   // (a goal successor relaxes the goal state)
                 // While the waypoint lanes work: everything of getOrCreateState that does not need their verdict.  Among the
                 // CANDIDATES (edges within limits) -- two with the same unknown coordinate (the lower primitive creates the
                 // state), two whose probing ended at the same empty slot -- and the heap's ancestors for the pushes to come.
@@ -721,11 +721,11 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 if (is_new) {
                     id = R.nstates + __popcll(m_new & below);
                     if (!clash) table_store_own(table, pr.free_slot, (const LDS_AS int*)X.coord[lane], nv, id);
-                    for (int v = 0; v < nv; ++v) { P->coord[(size_t)id * nv + v] = X.coord[lane][v]; P->q[(size_t)id * nv + v] = X.sq[lane][v]; }
+                    for (int v = 0; v < nv; ++v) { as_global(P->coord)[(size_t)id * nv + v] = X.coord[lane][v]; as_global(P->q)[(size_t)id * nv + v] = X.sq[lane][v]; }
                     ss.h = (unsigned int)b.h;
                     sstate_reinit(ss, R.call_number);
-                    sstate_store(&P->st[id], ss, true);              // (what the relaxation changes is stored again behind it)
-                    P->done_off[id] = -1;
+                    sstate_store(&as_global(P->st)[id], ss, true);              // (what the relaxation changes is stored again behind it)
+                    as_global(P->done_off)[id] = -1;
                 }
                 {
                     unsigned long long m_clash = __ballot(clash);
@@ -750,12 +750,11 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     sid = goal_succ ? 0 : id;      // a goal successor is reported as the goal id (manip_lattice.cpp:283-296)
                     cost = A.cost[lane];
                     if (goal_succ) ss = goal_ss;
-                    SmplxSucc sc;
-                    sc.id = sid;
-                    sc.cost_prim = cost | (lane << 24);
-                    P->succ[R.n_succ + __popcll(m_valid & below)] = sc;
+                    // (id, cost | primitive << 24) as one 8-byte store
+                    ((SMPLX_GLOBAL_AS unsigned long long*)as_global(P->succ))[R.n_succ + __popcll(m_valid & below)] =
+                        (unsigned long long)(unsigned int)sid | ((unsigned long long)(unsigned int)(cost | (lane << 24)) << 32);
                 }
-                if (lane == 0) { P->done_off[m] = R.n_succ; P->done_cnt[m] = cnt | (evals << 8); }
+                if (lane == 0) { as_global(P->done_off)[m] = R.n_succ; as_global(P->done_cnt)[m] = cnt | (evals << 8); }
                 R.n_succ += cnt;
                 R.nstates += __popcll(m_new);
                 R.gpu_evals += evals;
@@ -772,10 +771,11 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 evals = dcnt >> 8;
                 valid = lane < cnt;
                 if (valid) {
-                    const SmplxSucc sc = P->succ[off + lane];
-                    sid = sc.id;
-                    cost = sc.cost_prim & 0xFFFFFF;
-                    ss = sstate_load(&P->st[sid]);
+                    const unsigned long long sc = ((const SMPLX_GLOBAL_AS unsigned long long*)as_global(P->succ))[off + lane];
+                    const int sc_cost_prim = (int)(unsigned int)(sc >> 32);
+                    sid = (int)(unsigned int)sc;
+                    cost = sc_cost_prim & 0xFFFFFF;
+                    ss = sstate_load(&as_global(P->st)[sid]);
                 }
                 ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, cnt);
                 __syncthreads();                                     // B
@@ -820,7 +820,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     if ((itc_r >> 16) != (unsigned int)R.call_number) {
                         // reinitSearchState: not touched in this call (and so not in OPEN)
                         if (lane == r) { sstate_reinit(ss, R.call_number); dirty = true; }
-                        if (lane == 0) P->st[id].heap_index = 0;
+                        if (lane == 0) as_global(P->st)[id].heap_index = 0;
                         g_r = SMPLX_INFINITECOST; itc_r = (unsigned int)R.call_number << 16; flags_r = 0;
                     }
                     const int new_cost = (int)(eg + (unsigned int)cj);
@@ -835,7 +835,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         // the sifts keep it current
                         int hi = 0;
                         if (reached_before || !ac_complete) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // earlier sifts' stores have landed
-                        if (reached_before) hi = P->st[id].heap_index;
+                        if (reached_before) hi = as_global(P->st)[id].heap_index;
                         const hent_t e = hent_make(f, id);
                         if (hi != 0) {
                             if (flags_r & 1u) heap_refresh_duplicates_wave(H, W, lane, R.heap_size, id, f);
@@ -846,12 +846,12 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                             heap_sift_up_wave(H, W, lane, R.heap_size, e, true);
                         }
                     } else {
-                        if (lane == 0) P->incons[R.n_incons] = id;      // (never marked: arastar.cpp:563-565)
+                        if (lane == 0) as_global(P->incons)[R.n_incons] = id;      // (never marked: arastar.cpp:563-565)
                         ++R.n_incons;
                     }
                 }
             }
-            if (dirty && valid && alias < 0) sstate_store(&P->st[sid], ss, false);
+            if (dirty && valid && alias < 0) sstate_store(&as_global(P->st)[sid], ss, false);
             if (lane == 0) W.ac_nlev = 0;
             ++R.num;
             SK_TICK(4);
@@ -868,9 +868,9 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     solved = 0; cost = 0; n_path = 0;
                 } else {
                     int n = 0;
-                    for (int sid = 0; sid >= 0 && n < P->cap_path; sid = P->st[sid].bp) P->path[n++] = sid;
+                    for (int sid = 0; sid >= 0 && n < P->cap_path; sid = as_global(P->st)[sid].bp) as_global(P->path)[n++] = sid;
                     n_path = n;
-                    cost = (int)P->st[0].g;
+                    cost = (int)as_global(P->st)[0].g;
                     solved = 1;
                 }
                 R.phase = 4;
@@ -908,8 +908,8 @@ k_search_table_fill(const SmplxSpaceDev* __restrict__ Sq, const int* __restrict_
         const int* c = coord + (size_t)id * nvars;
         unsigned int k = smplx_coord_hash(c, nvars) & T.mask;
         while (true) {
-            int* sl = T.slots + (size_t)k * T.stride;
-            if (atomicCAS(&sl[0], 0, -(id + 1)) == 0) {
+            SMPLX_GLOBAL_AS int* sl = as_global(T.slots) + (size_t)k * T.stride;
+            if (atomicCAS((int*)&sl[0], 0, -(id + 1)) == 0) {
                 for (int v = 0; v < nvars; ++v) sl[1 + v] = c[v];
                 __threadfence();
                 __atomic_store_n(&sl[0], id + 1, __ATOMIC_RELAXED);
@@ -934,8 +934,8 @@ k_heap_ops(const int* __restrict__ ops, int nops, int lh, unsigned long long* __
     __shared__ SearchLds W;
     HeapRef H;
     H.lds = (LDS_AS hent_t*)smem;
-    H.hbm = heap_hbm;
-    H.st = st;
+    H.hbm = as_global(heap_hbm);
+    H.st = as_global(st);
     H.lh = lh;
     const int lane = threadIdx.x;
     if (lane == 0) W.ac_nlev = 0;

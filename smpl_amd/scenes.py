@@ -494,7 +494,10 @@ def shard_range(rank: int, world: int, total: int = 1024, per_rank: int = 128):
 
 
 # ----------------------------------------------------------------------------
-# K2 micro-benchmark inputs: the reference's own scheme (sbpl_collision_checking_test/src/benchmark_cc.cpp:280-301)
+# K2 micro-benchmark inputs: the same DISTRIBUTION as sbpl_collision_checking_test/src/benchmark_cc.cpp:280-301 (one
+# uniform_real_distribution per variable), with the engine and seed SURVEY 8d names (std::mt19937_64, 12345).  The reference
+# binary draws from a default-seeded std::default_random_engine (benchmark_cc.cpp:165), so its exact states differ, and no
+# reference fixture pins valid_fraction or the lookup tally: K2 parity is against the oracle only.
 # ----------------------------------------------------------------------------
 
 class MT19937_64:
@@ -552,7 +555,8 @@ class MT19937_64:
 
 def benchmark_states(limits, n: int = 1 << 20, seed: int = 12345) -> np.ndarray:
     """n joint states q ~ U[limits], one uniform_real_distribution per variable drawn in variable order for each state
-    (benchmark_cc.cpp:280-301 scheme), std::mt19937_64 seeded with 12345 (SURVEY 8d K2 micro-benchmark)."""
+    (same distribution as benchmark_cc.cpp:280-301), SURVEY-specified engine and seed: std::mt19937_64, 12345 (SURVEY 8d K2
+    micro-benchmark).  Not the states the reference binary would check (it seeds differently); parity is against the oracle."""
     g = MT19937_64(seed)
     nv = len(limits)
     u = g.raw(n * nv).astype(np.float64) * (1.0 / 18446744073709551616.0)
