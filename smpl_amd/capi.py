@@ -470,7 +470,7 @@ class Space:
         lib().smplx_search_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         _chk(lib().smplx_search_counters(self.h, out))
         names = ["searches", "grows", "dup_pushes", "t_idle", "t_select_pop", "t_evaluate", "t_commit", "t_relax", "t_reorder", "t_launch_io",
-                 "device_states", "heap_cache_entries"]
+                 "device_states", "heap_cache_entries", "spec_rounds", "spec_hits"]
         return {n: int(out[i]) for i, n in enumerate(names)}
 
     def set_search_capacity(self, states):

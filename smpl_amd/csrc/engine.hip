@@ -1367,6 +1367,8 @@ int smplx_search_counters(const smplx_space* s, int64_t out[16])
     for (int k = 0; k < 7; ++k) out[3 + k] = D.ticks[k];
     out[10] = D.h.nstates;
     out[11] = search_heap_cache_entries(s, nullptr);
+    out[12] = D.ticks[7] >> 32;            // evaluation rounds opened on a guess of the next pop
+    out[13] = D.ticks[7] & 0xFFFFFFFFll;   // ... that the pop confirmed
     return SMPLX_OK;
 }
 

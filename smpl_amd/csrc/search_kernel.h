@@ -35,7 +35,8 @@ enum { SA_EVAL = 0, SA_SKIP = 1, SA_REORDER = 2, SA_EXIT = 3 };
 
 // what the waves of the block share
 struct SearchLds {
-    int action;                            // the step, published before its first barrier
+    int action;                            // the round, published before its first barrier
+    int buf;                               // ... and the ExpandLds it works on
     double reorder_eps;
     int reorder_size, reorder_dups;
     // ancestors of the slots the pushes of a relaxation will take, as far as they lie in HBM: level j (1 = parents) holds
@@ -386,10 +387,10 @@ extern "C" __global__ void __launch_bounds__(512)
 k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, int* __restrict__ status_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ ExpandLds X;
+    __shared__ ExpandLds Xb[2];                  // two evaluations can be open: the one being committed and the next, speculative one
     __shared__ SearchLds W;
     __shared__ SmplxSearchDev Ph;                // the query's header as the launch found it: pointers, capacities, parameters
-    static_assert(sizeof(ExpandLds) + sizeof(SearchLds) + sizeof(SmplxSearchDev) <= SMPLX_SEARCH_STATIC_LDS, "engine.hip budgets this much static LDS");
+    static_assert(2 * sizeof(ExpandLds) + sizeof(SearchLds) + sizeof(SmplxSearchDev) <= SMPLX_SEARCH_STATIC_LDS, "engine.hip budgets this much static LDS");
     const SmplxSpaceDev* Sq = stab[blockIdx.x];
     const SmplxSpaceDev* S = stab[0];            // scene, robot and primitives are shared by the queries of a launch
     SmplxSearchDev* const Pd = Sq->search;
@@ -402,7 +403,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
         }
     }
     for (int i = t; i < (int)(sizeof(SmplxSearchDev) / 4); i += blockDim.x) ((int*)&Ph)[i] = ((const int*)Pd)[i];
-    if (t == 0) { W.action = SA_SKIP; W.ac_nlev = 0; }
+    if (t == 0) { W.action = SA_SKIP; W.buf = 0; W.ac_nlev = 0; }
     __syncthreads();
     const SmplxSearchDev* const P = &Ph;         // read-only view; what changes lives in the search wave and goes back to Pd at the end
     ModelLds Mv;
@@ -444,7 +445,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             __syncthreads();                                       // A: the step is published
             const int action = W.action;
             if (action == SA_EXIT) break;
-            if (action == SA_EVAL) expand_config_lane(M, L, A, Sq, grid, X, t, ncfg);
+            if (action == SA_EVAL) expand_config_lane(M, L, A, Sq, grid, Xb[W.buf], t, ncfg);
             if (action == SA_REORDER) {
                 const int size = W.reorder_size;
                 const double eps = W.reorder_eps;
@@ -506,6 +507,16 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
         // (bfs_heuristic.cpp:129-138 / 355-366: both read the BFS cell of the same planning-link position)
         const int cpc = bfs.cost_per_cell;
         const bool gd_from_h = cpc > 0 && (32767 % cpc) != 0;
+        // The next expansion, started early.  An evaluation round (barrier A .. barrier B) keeps the config waves busy for
+        // ~14 us while this wave only fills in the bookkeeping, and committing and relaxing a step (~7 us) plus the next pop
+        // (~4 us) kept THEM idle.  GetSuccs is a pure function of a state's joint values, so as soon as the verdicts of a
+        // step are in, this wave guesses the state the next pop will return -- the best new successor, if it beats the top
+        // of OPEN -- and opens the round for it in the other ExpandLds; the relaxation and the pop run beside it.  A right
+        // guess is adopted (the round is already under way), a wrong one is waited out and dropped: results never depend
+        // on it.  pend: the state whose round is open and not joined yet (-1: none), pbuf its buffer, p_act its lanes.
+        int pend = -1, pbuf = 0;
+        bool p_act = false;
+        long long spec_issued = 0, spec_hits = 0;
 
         while (true) {
             // =========================== what happens next (ARAStar::replan / improvePath) ===========================
@@ -555,6 +566,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 action = SA_EVAL;
             }
 
+            if (action != SA_EVAL && pend >= 0) { __syncthreads(); pend = -1; }      // B of a round nobody will use
             if (action == SA_EXIT) {
                 if (lane == 0) W.action = SA_EXIT;
                 __syncthreads();                                   // A
@@ -607,11 +619,30 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             const hent_t last = hget(H, R.heap_size);
             const int off = as_global(P->done_off)[m];                          // >= 0: expanded before (a later ARA* iteration)
             const int dcnt = as_global(P->done_cnt)[m];
-            if (lane < nv) X.parent[lane] = as_global(P->q)[(size_t)m * nv + lane];
-            if (lane < nprims) { X.edge_bad[lane] = 0; X.edge_lk[lane] = 0; }
-            if (lane == 0) { X.state_bad = 0; X.state_lookups = 0; as_global(P->st)[m].heap_index = 0; }
+            const bool use_spec = pend == m && off < 0;                         // (only states never expanded are guessed)
+            const int cur = use_spec ? pbuf : (pend >= 0 ? pbuf ^ 1 : 0);
+            ExpandLds& X = Xb[cur];
+            if (!use_spec) {
+                if (lane < nv) X.parent[lane] = as_global(P->q)[(size_t)m * nv + lane];
+                if (lane < nprims) { X.edge_bad[lane] = 0; X.edge_lk[lane] = 0; }
+                if (lane == 0) { X.state_bad = 0; X.state_lookups = 0; }
+            }
+            if (lane == 0) as_global(P->st)[m].heap_index = 0;
             --R.heap_size;
             if (R.heap_size >= 1) heap_sift_down_wave(H, lane, 1, R.heap_size, last);
+            // the new top of OPEN is what the NEXT pop returns unless this step puts something above it: its joint values and
+            // heuristic are requested now and looked at when the guess is made (below), a whole evaluation later
+            int top_id = -1, top_off = 0;
+            unsigned int top_f = 0xFFFFFFFFu, top_h = 0;
+            double top_q = 0.0;
+            if (R.heap_size >= 1) {
+                const hent_t tp = hget(H, 1);
+                top_id = hent_id(tp);
+                top_f = hent_f(tp);
+                top_off = as_global(P->done_off)[top_id];
+                top_h = as_global(P->st)[top_id].h;
+                if (lane < nv) top_q = as_global(P->q)[(size_t)top_id * nv + lane];
+            }
             const unsigned int eg = sm.g;
             if (lane == 0) {
                 *(SMPLX_GLOBAL_AS unsigned int*)&as_global(P->st)[m].iteration_closed = ((unsigned int)R.iteration & 0xFFFFu) | ((unsigned int)sm.call_number << 16);
@@ -630,22 +661,31 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
 
             if (off < 0) {
                 // ---- GetSuccs loop body (manip_lattice.cpp:254-305): successors' joint values, then the waypoint lanes ----
-                SMPLX_WAVE_SYNC();                                   // X.parent is complete
-                double gd;
-                if (gd_from_h) {
-                    const int hh = (int)sm.h;
-                    gd = hh == 32767 ? (double)0x7FFFFFFF * grid.res : (double)(hh / cpc) * grid.res;
-                } else {
-                    double g1 = 0.0;
-                    if (lane == 0) g1 = expand_goal_distance(M, grid, bfs, X);
-                    const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
-                    gd = __longlong_as_double((long long)bits);
-                }
                 const bool in = lane < nprims;
-                const bool act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd, A.type[lane]);
-                if (act) expand_successor_values(M, A, Sq, X, lane);
-                if (lane == 0) { X.goal_dist = gd; W.action = SA_EVAL; }
-                __syncthreads();                                     // A
+                bool act;
+                if (use_spec) {
+                    // the round for this state is open already: its successor values are in X, its lanes at work
+                    act = p_act;
+                    pend = -1;
+                    ++spec_hits;
+                } else {
+                    SMPLX_WAVE_SYNC();                               // X.parent is complete
+                    double gd;
+                    if (gd_from_h) {
+                        const int hh = (int)sm.h;
+                        gd = hh == 32767 ? (double)0x7FFFFFFF * grid.res : (double)(hh / cpc) * grid.res;
+                    } else {
+                        double g1 = 0.0;
+                        if (lane == 0) g1 = expand_goal_distance(M, grid, bfs, X);
+                        const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
+                        gd = __longlong_as_double((long long)bits);
+                    }
+                    act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd, A.type[lane]);
+                    if (act) expand_successor_values(M, A, Sq, X, lane);
+                    if (pend >= 0) { __syncthreads(); pend = -1; }   // B of the round that guessed wrong
+                    if (lane == 0) { X.goal_dist = gd; W.action = SA_EVAL; W.buf = cur; }
+                    __syncthreads();                                 // A
+                }
                 BookLane b;
                 b.limits_ok = false; b.W = 0; b.h = 0; b.is_goal = 0;
                 unsigned int hash = 0;
@@ -696,8 +736,47 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 int dup_of = find_dups(c_unknown, __ballot(c_unknown));
                 bool clash = find_clash(c_unknown && dup_of < 0, __ballot(c_unknown && dup_of < 0));
                 ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, __popcll(__ballot(cand)));
+                // ---- while the waypoint lanes finish: the round of the most likely next state, the top of OPEN, is got ready in
+                // the other buffer (its successors' joint values), so that it can be opened the moment this round closes ----
+                const int nxt = cur ^ 1;
+                bool top_ready = false, top_act = false;
+                if (top_id > 0 && top_off < 0 && top_f < R.goal_f && R.steps_left > 0) {
+                    ExpandLds& Y = Xb[nxt];
+                    if (lane < nv) Y.parent[lane] = top_q;
+                    if (lane < nprims) { Y.edge_bad[lane] = 0; Y.edge_lk[lane] = 0; }
+                    if (lane == 0) { Y.state_bad = 0; Y.state_lookups = 0; }
+                    SMPLX_WAVE_SYNC();                               // Y.parent is complete
+                    double gd2;
+                    if (gd_from_h) {
+                        const int hh = (int)top_h;
+                        gd2 = hh == 32767 ? (double)0x7FFFFFFF * grid.res : (double)(hh / cpc) * grid.res;
+                    } else {
+                        double g1 = 0.0;
+                        if (lane == 0) g1 = expand_goal_distance(M, grid, bfs, Y);
+                        const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
+                        gd2 = __longlong_as_double((long long)bits);
+                    }
+                    top_act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd2, A.type[lane]);
+                    if (top_act) expand_successor_values(M, A, Sq, Y, lane);
+                    if (lane == 0) Y.goal_dist = gd2;
+                    top_ready = true;
+                }
                 __syncthreads();                                     // B: the waypoint verdicts have landed
                 SK_TICK(2);
+                {
+                    // No edge that could create a state has a key below the top's (whatever the verdicts say): the next pop
+                    // returns that top, and its round opens at once.  Otherwise the guess waits for the verdicts (below).
+                    const bool maybe_new = cand && pr.id < 0 && !b.is_goal;
+                    const unsigned int fj = maybe_new ? search_key(R.curr_eps, eg + (unsigned int)A.cost[lane], (unsigned int)b.h) : 0xFFFFFFFFu;
+                    if (top_ready && __ballot(maybe_new && fj < top_f) == 0ull) {
+                        if (lane == 0) { W.action = SA_EVAL; W.buf = nxt; }
+                        __syncthreads();                             // A of the guessed round
+                        pend = top_id;
+                        pbuf = nxt;
+                        p_act = top_act;
+                        ++spec_issued;
+                    }
+                }
                 int lookups = 0;
                 const int flags = in ? expand_verdict(A, X, lane, act, b, lookups) : SMPLX_F_INACTIVE;
                 valid = (flags & SMPLX_F_VALID) != 0;
@@ -755,6 +834,45 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         (unsigned long long)(unsigned int)sid | ((unsigned long long)(unsigned int)(cost | (lane << 24)) << 32);
                 }
                 if (lane == 0) { as_global(P->done_off)[m] = R.n_succ; as_global(P->done_cnt)[m] = cnt | (evals << 8); }
+                if (pend < 0) {
+                    // ---- the guess (see above): the new successor with the least f if it beats the top of OPEN (a push does
+                    // not pass an equal key: intrusive_heap.hpp:346-365), else that top ----
+                    const bool cand = valid && is_new && !goal_succ;
+                    const unsigned int fj = cand ? search_key(R.curr_eps, eg + (unsigned int)cost, ss.h) : 0xFFFFFFFFu;
+                    unsigned long long key = ((unsigned long long)fj << 8) | (unsigned long long)lane;      // ties: the lower primitive
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned long long other = __shfl_xor(key, o);
+                        key = other < key ? other : key;
+                    }
+                    const unsigned int fbest = (unsigned int)(key >> 8);
+                    const int jbest = (int)(key & 0xFFull);
+                    const bool guess_succ = fbest != 0xFFFFFFFFu && fbest < top_f && fbest < R.goal_f;
+                    const bool guess_top = !guess_succ && top_id > 0 && top_off < 0 && top_f < R.goal_f;
+                    if ((guess_succ || guess_top) && R.steps_left > 0) {
+                        ExpandLds& Y = Xb[nxt];
+                        if (lane < nv) Y.parent[lane] = guess_succ ? X.sq[jbest][lane] : top_q;
+                        if (lane < nprims) { Y.edge_bad[lane] = 0; Y.edge_lk[lane] = 0; }
+                        if (lane == 0) { Y.state_bad = 0; Y.state_lookups = 0; }
+                        SMPLX_WAVE_SYNC();                           // Y.parent is complete
+                        double gd2;
+                        if (gd_from_h) {
+                            const int hh = guess_succ ? wave_rl((int)ss.h, jbest) : (int)top_h;
+                            gd2 = hh == 32767 ? (double)0x7FFFFFFF * grid.res : (double)(hh / cpc) * grid.res;
+                        } else {
+                            double g1 = 0.0;
+                            if (lane == 0) g1 = expand_goal_distance(M, grid, bfs, Y);
+                            const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
+                            gd2 = __longlong_as_double((long long)bits);
+                        }
+                        p_act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd2, A.type[lane]);
+                        if (p_act) expand_successor_values(M, A, Sq, Y, lane);
+                        if (lane == 0) { Y.goal_dist = gd2; W.action = SA_EVAL; W.buf = nxt; }
+                        __syncthreads();                             // A of the guessed round
+                        pend = guess_succ ? wave_rl(sid, jbest) : top_id;
+                        pbuf = nxt;
+                        ++spec_issued;
+                    }
+                }
                 R.n_succ += cnt;
                 R.nstates += __popcll(m_new);
                 R.gpu_evals += evals;
@@ -764,9 +882,8 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     R.lookups += wave_rl(lk, 0);
                 }
             } else {
-                // ---- GetSuccs of a state expanded before: the committed list ----
-                if (lane == 0) W.action = SA_SKIP;
-                __syncthreads();                                     // A
+                // ---- GetSuccs of a state expanded before: the committed list (no evaluation round) ----
+                if (pend >= 0) { __syncthreads(); pend = -1; }       // B of the round that guessed wrong
                 cnt = dcnt & 0xFF;
                 evals = dcnt >> 8;
                 valid = lane < cnt;
@@ -778,7 +895,6 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     ss = sstate_load(&as_global(P->st)[sid]);
                 }
                 ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, cnt);
-                __syncthreads();                                     // B
                 SK_TICK(2);
             }
 
@@ -884,6 +1000,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             Pd->status = R.status; Pd->grow_what = R.grow_what;
             Pd->committed_evals = R.committed_evals; Pd->gpu_evals = R.gpu_evals; Pd->lookups = R.lookups;
             SK_TICK(6);
+            ticks[7] += (spec_issued << 32) + spec_hits;            // rounds opened on a guess | guesses the next pop confirmed
             for (int k = 0; k < 8; ++k) Pd->ticks[k] = ticks[k];
             if (status_out) status_out[blockIdx.x] = R.status;
             W.reorder_size = R.heap_size;                           // (for the write-back of the LDS part below)

@@ -16,7 +16,7 @@ def ticks(sp):
     c = sp.search_counters()
     tot = sum(v for k, v in c.items() if k.startswith("t_")) or 1
     return ", ".join(f"{k[2:]} {v * 1e-5:.1f} ms ({100 * v / tot:.0f}%)" for k, v in c.items() if k.startswith("t_")) + \
-        f"; grows {c['grows']}, dup pushes {c['dup_pushes']}, heap cache {c['heap_cache_entries']}"
+        f"; grows {c['grows']}, dup pushes {c['dup_pushes']}, heap cache {c['heap_cache_entries']}, guessed rounds {c['spec_rounds']} of which used {c['spec_hits']}"
 
 
 for mode in ("device", "host"):
