@@ -10,13 +10,15 @@
 
 #define SMPLX_BLOCK 128          // 2 waves; per-thread LDS scratch keeps ~4 blocks per CU resident
 #define SMPLX_STACK_BYTES 32
-#define SMPLX_SEARCH_STATIC_LDS (30 * 1024)   // static LDS of k_search (2 x ExpandLds + SearchLds + header copy), an upper bound
+#define SMPLX_SEARCH_STATIC_LDS (39 * 1024)   // static LDS of k_search (2 x ExpandLds + SearchLds + header and primitives copies), an upper bound
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
 // dynamic LDS bytes: the packed model, plus (collision kernels) per-thread scratch
 // small-batch kernel: 7 waypoint lanes per primitive + the state's own lane in whole "config" waves, then one more wave
 // whose lanes are the primitives' bookkeeping lanes + the goal-distance lane (nprims + 1 <= 64)
 static inline int smplx_small_block(int nprims) { return ((nprims * 7 + 1) + 63) / 64 * 64 + 64; }
+// k_search: the same, plus a wave that works out the successors' heuristics beside the search wave where 512 threads allow it
+static inline int smplx_search_block(int nprims) { const int b = smplx_small_block(nprims); return b + 64 <= 512 ? b + 64 : b; }
 static inline size_t smplx_lds_bytes_n(size_t blob_bytes, int nroot, int nslots, int nvars, int nthreads)
 {
     return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * nthreads + (size_t)SMPLX_STACK_BYTES * nthreads;

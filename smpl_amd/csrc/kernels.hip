@@ -1840,16 +1840,16 @@ struct ExpandLds {
 // k_search (search_kernel.h) put them together around their own barriers ----
 
 // can the primitive produce an action at all (a snap needs a joint-space goal: manip_lattice_action_space.cpp:551-559)
-__device__ __forceinline__ bool prim_has_action(const SmplxActionsDev& A, const SmplxSpaceDev* __restrict__ Sq, int p)
+__device__ __forceinline__ bool prim_has_action(const SmplxActionsDev& A, const SmplxGoalDev& G, int p)
 {
     const int ty = A.type[p];
-    return ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && Sq->goal.type == SMPLX_GOAL_JOINT);
+    return ty == SMPLX_MP_LONG || ty == SMPLX_MP_SHORT || (ty == SMPLX_MP_SNAP_XYZ_RPY && G.type == SMPLX_GOAL_JOINT);
 }
 
 // bookkeeping lane of primitive p, first half: the successor's joint values -> X.sq[p] (applyMotionPrimitive,
 // manip_lattice_action_space.cpp:575-621)
 __device__ __forceinline__ void expand_successor_values(const ModelLds* __restrict__ M, const SmplxActionsDev& A,
-                                                        const SmplxSpaceDev* __restrict__ Sq, ExpandLds& X, int p)
+                                                        const SmplxGoalDev& G, ExpandLds& X, int p)
 {
     const int nv = MV_NVARS(M);
     const double* parent = X.parent;
@@ -1870,7 +1870,7 @@ __device__ __forceinline__ void expand_successor_values(const ModelLds* __restri
         }
     } else {
         MV_UNROLL
-        for (int v = 0; v < nv; ++v) X.sq[p][v] = Sq->goal.angles[v];   // :551-559
+        for (int v = 0; v < nv; ++v) X.sq[p][v] = G.angles[v];   // :551-559
     }
 }
 
@@ -1909,12 +1909,12 @@ __device__ __forceinline__ int expand_waypoint_count(const ModelLds* __restrict_
 // config lane c of the block: c < ncfg - 1: lane (p, slot) checks waypoints slot+1, slot+8, ... of edge p (an edge longer
 // than 7 waypoints wraps around its lanes); c == ncfg - 1: the state itself (waypoint 0 of every edge)
 __device__ __forceinline__ void expand_config_lane(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxActionsDev& A,
-                                                   const SmplxSpaceDev* __restrict__ Sq, const SmplxGridDev& grid, ExpandLds& X, int c, int ncfg)
+                                                   const SmplxGoalDev& G, const SmplxGridDev& grid, ExpandLds& X, int c, int ncfg)
 {
     const double* parent = X.parent;
     if (c < ncfg - 1) {
         const int p = c / SMPLX_SMALL_LANES, slot = c % SMPLX_SMALL_LANES;
-        if (prim_has_action(A, Sq, p) && mprim_active(A, X.goal_dist, A.type[p])) {
+        if (prim_has_action(A, G, p) && mprim_active(A, X.goal_dist, A.type[p])) {
             const double* sq = X.sq[p];
             if (check_joint_limits(M, sq)) {
                 const int Wc = expand_waypoint_count(M, parent, sq);
@@ -1956,31 +1956,31 @@ __device__ __forceinline__ void expand_book_coords(const ModelLds* __restrict__ 
     }
 }
 __device__ __forceinline__ void expand_book_goal(const ModelLds* __restrict__ M, const SmplxGridDev& grid, const SmplxBfsDev& bfs,
-                                                 const SmplxSpaceDev* __restrict__ Sq, const ExpandLds& X, int p, BookLane& r)
+                                                 const SmplxGoalDev& G, const ExpandLds& X, int p, BookLane& r)
 {
     if (!r.limits_ok) return;
     const int nv = MV_NVARS(M);
     double pw[3];
     planning_fk(M, X.sq[p], pw);
-    if (Sq->goal.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
+    if (G.type == SMPLX_GOAL_JOINT) {      // manip_lattice.cpp:1596-1606
         r.is_goal = 1;
         MV_UNROLL
         for (int v = 0; v < nv; ++v)
-            if (fabs((double)(X.coord[p][v] - Sq->goal.coord[v])) > Sq->goal.angle_tol[v]) r.is_goal = 0;
+            if (fabs((double)(X.coord[p][v] - G.coord[v])) > G.angle_tol[v]) r.is_goal = 0;
     } else {                                      // XYZ goal :1672-1687
-        r.is_goal = fabs(pw[0] - Sq->goal.xyz[0]) <= Sq->goal.xyz_tol[0] && fabs(pw[1] - Sq->goal.xyz[1]) <= Sq->goal.xyz_tol[1] &&
-                    fabs(pw[2] - Sq->goal.xyz[2]) <= Sq->goal.xyz_tol[2];
+        r.is_goal = fabs(pw[0] - G.xyz[0]) <= G.xyz_tol[0] && fabs(pw[1] - G.xyz[1]) <= G.xyz_tol[1] &&
+                    fabs(pw[2] - G.xyz[2]) <= G.xyz_tol[2];
     }
     int c[3];
     world_to_cell(grid, pw, c);
     r.h = bfs_cost_to_goal(bfs, c);
 }
 __device__ __forceinline__ BookLane expand_book_lane(const ModelLds* __restrict__ M, const SmplxGridDev& grid, const SmplxBfsDev& bfs,
-                                                     const SmplxSpaceDev* __restrict__ Sq, ExpandLds& X, int p)
+                                                     const SmplxGoalDev& G, ExpandLds& X, int p)
 {
     BookLane r;
     expand_book_coords(M, X, p, r);
-    expand_book_goal(M, grid, bfs, Sq, X, p, r);
+    expand_book_goal(M, grid, bfs, G, X, p, r);
     return r;
 }
 
@@ -2024,14 +2024,14 @@ __device__ __forceinline__ void expand_state_block(const ModelLds* __restrict__ 
         if (bp < nv) X.parent[bp] = parent_src[bp];
         SMPLX_WAVE_SYNC();
     }
-    const bool have_action = book && prim_has_action(A, Sq, bp);
-    if (have_action) expand_successor_values(M, A, Sq, X, bp);
+    const bool have_action = book && prim_has_action(A, Sq->goal, bp);
+    if (have_action) expand_successor_values(M, A, Sq->goal, X, bp);
     if (bp == nprims) X.goal_dist = expand_goal_distance(M, grid, bfs, X);
     __syncthreads();   // every lane of every edge can read its successor's joint values and the gate from LDS
     BookLane b;
     b.limits_ok = false; b.W = 0; b.h = 0; b.is_goal = 0;
-    if (t < book0) expand_config_lane(M, L, A, Sq, grid, X, t, ncfg);
-    else if (have_action) b = expand_book_lane(M, grid, bfs, Sq, X, bp);
+    if (t < book0) expand_config_lane(M, L, A, Sq->goal, grid, X, t, ncfg);
+    else if (have_action) b = expand_book_lane(M, grid, bfs, Sq->goal, X, bp);
     __syncthreads();   // the waypoint verdicts and the state's own check have landed in LDS
     if (book) {
         int lookups;

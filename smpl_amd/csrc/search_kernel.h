@@ -390,7 +390,9 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     __shared__ ExpandLds Xb[2];                  // two evaluations can be open: the one being committed and the next, speculative one
     __shared__ SearchLds W;
     __shared__ SmplxSearchDev Ph;                // the query's header as the launch found it: pointers, capacities, parameters
-    static_assert(2 * sizeof(ExpandLds) + sizeof(SearchLds) + sizeof(SmplxSearchDev) <= SMPLX_SEARCH_STATIC_LDS, "engine.hip budgets this much static LDS");
+    __shared__ SmplxGoalDev Gh;                  // ... and the goal
+    __shared__ SmplxActionsDev Ah;               // the primitives: read by the search wave several times per expansion, each read a round trip to L2 otherwise
+    static_assert(2 * sizeof(ExpandLds) + sizeof(SearchLds) + sizeof(SmplxSearchDev) + sizeof(SmplxActionsDev) + sizeof(SmplxGoalDev) <= SMPLX_SEARCH_STATIC_LDS, "engine.hip budgets this much static LDS");
     const SmplxSpaceDev* Sq = stab[blockIdx.x];
     const SmplxSpaceDev* S = stab[0];            // scene, robot and primitives are shared by the queries of a launch
     SmplxSearchDev* const Pd = Sq->search;
@@ -403,19 +405,23 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
         }
     }
     for (int i = t; i < (int)(sizeof(SmplxSearchDev) / 4); i += blockDim.x) ((int*)&Ph)[i] = ((const int*)Pd)[i];
+    for (int i = t; i < (int)(sizeof(SmplxActionsDev) / 4); i += blockDim.x) ((int*)&Ah)[i] = ((const int*)&S->actions)[i];
+    for (int i = t; i < (int)(sizeof(SmplxGoalDev) / 4); i += blockDim.x) ((int*)&Gh)[i] = ((const int*)&Sq->goal)[i];
     if (t == 0) { W.action = SA_SKIP; W.buf = 0; W.ac_nlev = 0; }
     __syncthreads();
     const SmplxSearchDev* const P = &Ph;         // read-only view; what changes lives in the search wave and goes back to Pd at the end
+    const SmplxActionsDev& A = Ah;
+    const SmplxGoalDev& G = Gh;
+    const int nprims = A.nprims;
+    const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
+    const int book0 = (ncfg + 63) / 64 * 64;                  // first thread of the search wave
     ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv, blockDim.x);
+    ThreadLds L = setup_lds(S, smem, &Mv, book0);             // per-thread scratch for the config waves only (nobody else walks a chain through LDS)
     const ModelLds* M = &Mv;
-    const SmplxActionsDev& A = S->actions;
     const SmplxGridDev grid = S->grid;
     const SmplxBfsDev bfs = Sq->bfs;
     const SmplxTableDev table = Sq->table;
-    const int nprims = A.nprims, nv = MV_NVARS(M);
-    const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
-    const int book0 = (ncfg + 63) / 64 * 64;                  // first thread of the search wave
+    const int nv = MV_NVARS(M);
     HeapRef H;
     {
         // the heap cache sits behind the model and the per-thread scratch of the expansion (setup_lds)
@@ -426,7 +432,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
 #endif
         const int* hdr = reinterpret_cast<const int*>(S->model_blob);
         unsigned int off = (unsigned int)hdr[SMPLX_BH_BYTES] +
-                           (unsigned int)((3 * nroot_lds + 12 * Mv.nslots + Mv.nvars) * 8 + SMPLX_STACK_BYTES) * blockDim.x;
+                           (unsigned int)((3 * nroot_lds + 12 * Mv.nslots + Mv.nvars) * 8 + SMPLX_STACK_BYTES) * (unsigned int)book0;
         off = (off + 15u) & ~15u;
         H.lds = (LDS_AS hent_t*)((LDS_AS unsigned char*)smem + off);
         H.hbm = (SMPLX_GLOBAL_AS hent_t*)as_global(P->heap);
@@ -439,13 +445,32 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     }
     __syncthreads();
 
-    if (t < book0) {
-        // =============================== the config waves ===============================
+    // The wave behind the search wave, where the block has one (smplx_search_block): between the two barriers of a round it
+    // works out, for every primitive with an action, what the search wave needs of the successor beyond its coordinate --
+    // the heuristic (planning-link FK + BFS cell, ~3 us of dependent arithmetic for a lone wave) and the goal test -- and
+    // leaves them in X.h / X.flags.  The search wave's own work per expansion is what bounds the kernel.
+    const int help0 = book0 + 64;
+    const bool has_helper = (int)blockDim.x > help0;
+    if (t < book0 || t >= help0) {
+        // =============================== the config waves (and the helper wave) ===============================
         while (true) {
             __syncthreads();                                       // A: the step is published
             const int action = W.action;
             if (action == SA_EXIT) break;
-            if (action == SA_EVAL) expand_config_lane(M, L, A, Sq, grid, Xb[W.buf], t, ncfg);
+            if (action == SA_EVAL) {
+                ExpandLds& Xr = Xb[W.buf];
+                if (t < book0) expand_config_lane(M, L, A, G, grid, Xr, t, ncfg);
+                else {
+                    const int p = t - help0;
+                    if (p < nprims && Xr.lookups[p] != 0) {           // (lookups[p]: the search wave's "primitive p has an action here")
+                        BookLane r;
+                        expand_book_coords(M, Xr, p, r);             // (the search wave writes the same coordinates)
+                        expand_book_goal(M, grid, bfs, G, Xr, p, r);
+                        Xr.h[p] = r.h;
+                        Xr.flags[p] = r.is_goal;
+                    }
+                }
+            }
             if (action == SA_REORDER) {
                 const int size = W.reorder_size;
                 const double eps = W.reorder_eps;
@@ -680,9 +705,10 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
                         gd = __longlong_as_double((long long)bits);
                     }
-                    act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd, A.type[lane]);
-                    if (act) expand_successor_values(M, A, Sq, X, lane);
+                    act = in && prim_has_action(A, G, lane) && mprim_active(A, gd, A.type[lane]);
+                    if (act) expand_successor_values(M, A, G, X, lane);
                     if (pend >= 0) { __syncthreads(); pend = -1; }   // B of the round that guessed wrong
+                    if (in) X.lookups[lane] = act ? 1 : 0;
                     if (lane == 0) { X.goal_dist = gd; W.action = SA_EVAL; W.buf = cur; }
                     __syncthreads();                                 // A
                 }
@@ -698,9 +724,9 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         // a coordinate the table knows has its search state requested at once (it lands behind the waypoint lanes)
                         hash = coord_hash_lds((const LDS_AS int*)X.coord[lane], nv);
                         TableProbeLoads ld = table_probe_start(table, nv, hash);
-                        expand_book_goal(M, grid, bfs, Sq, X, lane, b);
+                        if (!has_helper) expand_book_goal(M, grid, bfs, G, X, lane, b);
                         pr = table_probe_finish(table, ld, (const LDS_AS int*)X.coord[lane], nv);
-                        if (pr.id >= 0 && !b.is_goal) ss = sstate_load(&as_global(P->st)[pr.id]);
+                        if (pr.id >= 0 && (has_helper || !b.is_goal)) ss = sstate_load(&as_global(P->st)[pr.id]);   // (a goal successor takes the goal's state below)
                     }
                 }
                 const SmplxSState goal_ss = sstate_load(&as_global(P->st)[0]);   // (a goal successor relaxes the goal state)
@@ -756,13 +782,15 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
                         gd2 = __longlong_as_double((long long)bits);
                     }
-                    top_act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd2, A.type[lane]);
-                    if (top_act) expand_successor_values(M, A, Sq, Y, lane);
+                    top_act = in && prim_has_action(A, G, lane) && mprim_active(A, gd2, A.type[lane]);
+                    if (top_act) expand_successor_values(M, A, G, Y, lane);
+                    if (in) Y.lookups[lane] = top_act ? 1 : 0;
                     if (lane == 0) Y.goal_dist = gd2;
                     top_ready = true;
                 }
                 __syncthreads();                                     // B: the waypoint verdicts have landed
                 SK_TICK(2);
+                if (has_helper && cand) { b.h = X.h[lane]; b.is_goal = X.flags[lane]; }
                 {
                     // No edge that could create a state has a key below the top's (whatever the verdicts say): the next pop
                     // returns that top, and its round opens at once.  Otherwise the guess waits for the verdicts (below).
@@ -864,8 +892,9 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                             const unsigned long long bits = wave_rl64((unsigned long long)__double_as_longlong(g1), 0);
                             gd2 = __longlong_as_double((long long)bits);
                         }
-                        p_act = in && prim_has_action(A, Sq, lane) && mprim_active(A, gd2, A.type[lane]);
-                        if (p_act) expand_successor_values(M, A, Sq, Y, lane);
+                        p_act = in && prim_has_action(A, G, lane) && mprim_active(A, gd2, A.type[lane]);
+                        if (p_act) expand_successor_values(M, A, G, Y, lane);
+                        if (in) Y.lookups[lane] = p_act ? 1 : 0;
                         if (lane == 0) { Y.goal_dist = gd2; W.action = SA_EVAL; W.buf = nxt; }
                         __syncthreads();                             // A of the guessed round
                         pend = guess_succ ? wave_rl(sid, jbest) : top_id;
