@@ -367,6 +367,53 @@ def main():
         out["k2"] = k2
         del dq, dv, dl
 
+        # ---- a second timed frontier whose edges DO collide: B valid states drawn uniformly within the limits (the K2
+        # generator, other seed) -- arms folded next to the table and the shelf, so that colliding edges, joint limits and the
+        # sparse side of the compaction are inside a timed step (the search frontier above is almost collision-free) ----
+        Qr_all = scenes.benchmark_states(scenes.ARM7_LIMITS, 4 * B, 777)
+        ok_r, _ = space.state_valid_batch(Qr_all)
+        Qr = np.ascontiguousarray(Qr_all[ok_r.astype(bool)][:B])
+        if Qr.shape[0] == B:
+            d_qr = torch.from_numpy(Qr).to(dev)
+            cnt_r = torch.zeros_like(d_cnt)
+
+            def step_random():
+                space.expand_batch_k5_device(d_qr.data_ptr(), B, d_flags.data_ptr(), d_coord.data_ptr(), d_sq.data_ptr(),
+                                             d_h.data_ptr(), d_cost.data_ptr(), d_lk.data_ptr(), d_id.data_ptr(), d_reca.data_ptr(), cap_k5,
+                                             d_recb.data_ptr(), cap_k5, d_btab.data_ptr(), d_tot.data_ptr(), d_work.data_ptr(),
+                                             cnt_r.data_ptr(), stream.cuda_stream)
+            for _ in range(5):
+                step_random()
+            torch.cuda.synchronize()
+            cnt_r.zero_()
+            nr = max(args.steps, 200)
+            tr0 = time.perf_counter()
+            for _ in range(nr):
+                step_random()
+            torch.cuda.synchronize()
+            tr1 = time.perf_counter()
+            ev_r, va_r, lkr_r, lkd_r, cf_r, sl_r = space.counters_read(cnt_r.data_ptr(), B)
+            flr = d_flags.cpu().numpy().reshape(B, M)
+            rf = {"states": f"{B} valid states q ~ U[limits] (K2 generator, seed 777)", "steps": nr,
+                  "ms_per_step": round(1e3 * (tr1 - tr0) / nr, 4), "successor_evaluations_per_s": round(ev_r / (tr1 - tr0), 1),
+                  "valid_fraction": round(va_r / max(ev_r, 1), 4),
+                  "edges_out_of_limits": int(((flr & 0x20) != 0).sum()), "edges_in_collision": int(((flr & 0x40) != 0).sum()),
+                  "edges_inactive": int(((flr & 0x10) != 0).sum()), "configs_per_launch": int(cf_r / nr)}
+            if Oracle is not None:
+                o = Oracle(cfg)
+                o.set_order(chain=True)
+                o.set_goal_joint(q_goal, cfg.goal_tol)
+                hc = d_h.cpu().numpy().reshape(B, M); cc = d_cost.cpu().numpy().reshape(B, M)
+                same = True
+                for i in range(64):
+                    e = o.eval_state(Qr[i])
+                    v = (e["flags"] & 1) != 0
+                    same = same and bool(np.array_equal(e["flags"], flr[i]) and np.array_equal(e["h"][v], hc[i][v]) and np.array_equal(e["cost"][v], cc[i][v]))
+                rf["parity"] = {"flags_h_cost_equal_on_first_64_states": same}
+                del o
+            out["random_frontier"] = rf
+            del d_qr, cnt_r
+
         # ---- the reference's own collision benchmark shape ("collision checks / s, PR2 right arm, uniformly
         # random joint states", benchmark_cc.cpp:234-301): the PR2 right arm built from data files (the reference's
         # collision_model_pr2.yaml + a URDF subset, tests/golden/) in an EMPTY world ----
