@@ -269,8 +269,8 @@ int smplx_get_succs(smplx_space* s, int id, int32_t* succs, int32_t* costs, int 
 /* optional: ids the caller expects to expand soon (top of OPEN); they ride along in the next batch.  A caller that
  * never hints (an unchanged SBPL planner) still gets frontier batches: the space mirrors the g-values the caller's
  * GetSuccs sequence implies (arastar.cpp:546-551) and lets the unevaluated states with the smallest g + w*h ride
- * along on every miss (env SMPLX_AUTO_SPECULATE = states per miss, default 96, 0 = off; SMPLX_AUTO_SPECULATE_W = w,
- * default 5).  Speculation never changes results: ids are assigned when the caller's own sequence commits a state. */
+ * along on every miss (env SMPLX_AUTO_SPECULATE = states per miss, default 96, 0 = off; w = 5).  Speculation never
+ * changes results: ids are assigned when the caller's own sequence commits a state. */
 int smplx_hint_frontier(smplx_space* s, const int32_t* ids, int n);
 /* GetSuccs has no way to report a failure to an SBPL caller (the successor list just stays empty, which reads as a
  * dead end): the first such error is kept on the space.  Returns SMPLX_OK or that error code; msg gets its text. */
