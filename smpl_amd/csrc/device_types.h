@@ -95,6 +95,9 @@ struct SmplxGridDev {
 //   [0, 512)     cell (lx, ly, lz) at lz * 64 + ly * 8 + lx
 //   [512, 896)   faces x = 0, x = 7 (index lz * 8 + ly), y = 0, y = 7 (lz * 8 + lx), z = 0, z = 7 (ly * 8 + lx), 64 each
 //   [896, 928)   edges (x, y) = (0, 0), (7, 0), (0, 7), (7, 7), index lz
+//   [928, 936)   the eight cells DIAGONALLY next to the brick's corners (they belong to eight other bricks, which write
+//                them here when they change: a visit reads one 32-byte sector of its own record instead of eight of others'),
+//                index cx | cy << 1 | cz << 2 (0 = the low side)
 // WALL 0x7FFFFFFF, UNDISCOVERED -1 as in the reference (bfs3d.h:48-51); cells beyond the grid in the last bricks are walls.
 // A distance carries the TAG of the BFS run that wrote it in its bits 28-30 (tag_word = tag << 28, tag 1..7, tag_mask =
 // 0xF0000000): a cell whose tag is not the current run's counts as UNDISCOVERED, so a new goal needs no pass over the records
@@ -103,7 +106,8 @@ struct SmplxGridDev {
 #define SMPLX_BFS_REC 1024
 #define SMPLX_BFS_FACES 512
 #define SMPLX_BFS_EDGES 896
-#define SMPLX_BFS_USED 928
+#define SMPLX_BFS_CORNERS 928
+#define SMPLX_BFS_USED 936
 struct SmplxBfsDev {
     int32_t dim_x, dim_y, dim_z, dim_xy;     // padded dims (bfs3d.cpp:61-66): what inBounds compares with
     int32_t cost_per_cell, tag_word;

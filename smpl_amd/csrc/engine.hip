@@ -403,7 +403,7 @@ int run_bfs(smplx_space* s, const double xyz[3])
     const int kShards = 16;
     const size_t list_ints = (size_t)kShards * nbricks;
     int32_t* lists = s->d_queue;
-    hipLaunchKernelGGL(k_bfs_brick_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, c[0], c[1], c[2], nbx, nby, lists, s->d_counts, tag_word);
+    hipLaunchKernelGGL(k_bfs_brick_seed, dim3(1), dim3(64), 0, s->stream, s->d_bfs, c[0], c[1], c[2], nbx, nby, nbz, lists, s->d_counts, tag_word);
     HIP_TRY(hipGetLastError());
     int pass = 0;
     std::vector<int32_t> cnt(3 * kShards * 32 + kBfsHistory);

@@ -74,7 +74,7 @@ __global__ void k_bfs_metric(SmplxGridDev grid, SmplxBfsDev bfs, const double* x
 __global__ void k_bfs_init(SmplxGridDev g, int wall_thr, int nbx, int nby, int nbz, int* dist);
 __global__ void k_bfs_reset(int* dist, size_t total);
 __global__ void k_bfs_export(SmplxBfsDev b, int* out);
-__global__ void k_bfs_brick_seed(int* dist, int cx, int cy, int cz, int nbx, int nby, int* list0, int* counts, int tag_word);
+__global__ void k_bfs_brick_seed(int* dist, int cx, int cy, int cz, int nbx, int nby, int nbz, int* list0, int* counts, int tag_word);
 __global__ void k_bfs_brick_wave(int* dist, int nbx, int nby, int nbz, const int* list_in, const int* counts_in, int* list_next,
                                  int* counts_next, int* counts_after, int shard_cap, int* queued_mine, int* queued_next, int* queue_size_out, int tag_word, int tag_mask);
 }

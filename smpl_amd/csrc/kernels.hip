@@ -2217,7 +2217,8 @@ k_sphere_positions(const SmplxSpaceDev* __restrict__ S, const double* __restrict
 #define SMPLX_BRICK 8
 #define SMPLX_BRICK_TILE (SMPLX_BRICK + 2)
 
-// local cell of slot s < SMPLX_BFS_USED of a record (interior, face copy or edge copy)
+// local cell of slot s < SMPLX_BFS_USED of a record (interior, face copy, edge copy, or -- with a coordinate of -1 or 8 -- the
+// diagonal neighbour's cell next to a corner)
 __device__ __forceinline__ void bfs_slot_cell(int s, int& lx, int& ly, int& lz)
 {
     if (s < SMPLX_BFS_FACES) { lz = s >> 6; ly = (s >> 3) & 7; lx = s & 7; return; }
@@ -2228,10 +2229,17 @@ __device__ __forceinline__ void bfs_slot_cell(int s, int& lx, int& ly, int& lz)
         else { lz = f == 4 ? 0 : 7; ly = a; lx = c; }
         return;
     }
-    const int k = (s - SMPLX_BFS_EDGES) >> 3;
-    lz = (s - SMPLX_BFS_EDGES) & 7;
-    lx = (k & 1) ? 7 : 0;
-    ly = (k & 2) ? 7 : 0;
+    if (s < SMPLX_BFS_CORNERS) {
+        const int k = (s - SMPLX_BFS_EDGES) >> 3;
+        lz = (s - SMPLX_BFS_EDGES) & 7;
+        lx = (k & 1) ? 7 : 0;
+        ly = (k & 2) ? 7 : 0;
+        return;
+    }
+    const int c = s - SMPLX_BFS_CORNERS;      // a neighbour's cell, one step outside the brick
+    lx = (c & 1) ? 8 : -1;
+    ly = (c & 2) ? 8 : -1;
+    lz = (c & 4) ? 8 : -1;
 }
 
 // every slot of a record that holds cell (lx, ly, lz) takes v
@@ -2247,10 +2255,22 @@ __device__ __forceinline__ void bfs_record_store_cell(int* __restrict__ rec, int
     if ((lx == 0 || lx == 7) && (ly == 0 || ly == 7)) rec[SMPLX_BFS_EDGES + (((ly == 7) ? 2 : 0) + ((lx == 7) ? 1 : 0)) * 8 + lz] = v;
 }
 
+// a CORNER cell of brick (bx, by, bz) also goes into the corner slot of the brick diagonally across it (device_types.h)
+__device__ __forceinline__ void bfs_push_corner(int* __restrict__ dist, int bx, int by, int bz, int nbx, int nby, int nbz,
+                                                int lx, int ly, int lz, int v)
+{
+    const int qx = bx + (lx == 7 ? 1 : -1), qy = by + (ly == 7 ? 1 : -1), qz = bz + (lz == 7 ? 1 : -1);
+    if (qx < 0 || qy < 0 || qz < 0 || qx >= nbx || qy >= nby || qz >= nbz) return;
+    // seen from there this brick lies on the low side of an axis where the cell is at 7
+    const int c = (lx == 7 ? 0 : 1) | ((ly == 7 ? 0 : 1) << 1) | ((lz == 7 ? 0 : 1) << 2);
+    dist[(size_t)((qz * nby + qy) * nbx + qx) * SMPLX_BFS_REC + SMPLX_BFS_CORNERS + c] = v;
+}
+
 // The halo of a brick beyond its six faces: 12 edges of 8 cells and 8 corners, piece e < 104.  Where piece e comes from (the
 // neighbour brick (ddx, ddy, ddz), the slot of that brick's record) and where it sits in the 10x10x10 tile: a z-parallel
 // edge from the neighbour's edge copies, an x- or y-parallel one from the face copy whose fastest index runs along it, a
-// corner from an edge copy.  Functions of e alone: a lane works them out once per launch.
+// corner from the corner slots of the brick's own record (the diagonal neighbours keep them current: bfs_push_corner).
+// Functions of e alone: a lane works them out once per launch.
 __device__ __forceinline__ void bfs_edge_piece(int e, int& ddx, int& ddy, int& ddz, int& src, int& pos)
 {
     constexpr int TL = SMPLX_BRICK_TILE, TP = SMPLX_BRICK_TILE * SMPLX_BRICK_TILE, HI = SMPLX_BRICK_TILE - 1;
@@ -2268,10 +2288,10 @@ __device__ __forceinline__ void bfs_edge_piece(int e, int& ddx, int& ddy, int& d
         ddx = s0 ? 1 : -1; ddy = 0; ddz = s1 ? 1 : -1;
         src = SMPLX_BFS_FACES + (s0 ? 0 : 1) * 64 + (s1 ? 0 : 7) * 8 + i;
         pos = (s1 ? HI : 0) * TP + (i + 1) * TL + (s0 ? HI : 0);
-    } else {                 // corners: e = 96 + (cx | cy << 1 | cz << 2)
+    } else {                 // corners: e = 96 + (cx | cy << 1 | cz << 2), from the corner slots of the brick's OWN record
         const int cx = i & 1, cy = (i >> 1) & 1, cz = (i >> 2) & 1;
-        ddx = cx ? 1 : -1; ddy = cy ? 1 : -1; ddz = cz ? 1 : -1;
-        src = SMPLX_BFS_EDGES + ((cy ? 0 : 2) + (cx ? 0 : 1)) * 8 + (cz ? 0 : 7);
+        ddx = 0; ddy = 0; ddz = 0;
+        src = SMPLX_BFS_CORNERS + i;
         pos = (cz ? HI : 0) * TP + (cy ? HI : 0) * TL + (cx ? HI : 0);
     }
 }
@@ -2290,7 +2310,7 @@ k_bfs_init(SmplxGridDev g, int wall_thr, int nbx, int nby, int nbz, int* __restr
             int lx, ly, lz;
             bfs_slot_cell(s, lx, ly, lz);
             const int cx = (int)(b % nbx) * 8 + lx, cy = (int)(b / nbx % nby) * 8 + ly, cz = (int)(b / ((size_t)nbx * nby)) * 8 + lz;
-            if (cx < g.n[0] && cy < g.n[1] && cz < g.n[2]) {
+            if (cx >= 0 && cy >= 0 && cz >= 0 && cx < g.n[0] && cy < g.n[1] && cz < g.n[2]) {      // (a corner slot can lie outside the grid: a wall)
                 const size_t brick = ((size_t)(cx >> 2) * g.bricks[1] + (cy >> 2)) * g.bricks[2] + (cz >> 2);
                 const int d2 = (int)g.d2[brick * 64 + ((cx & 3) << 4) + ((cy & 3) << 2) + (cz & 3)];
                 v = d2 <= wall_thr ? 0x7FFFFFFF : -1;
@@ -2325,7 +2345,7 @@ k_bfs_export(SmplxBfsDev b, int* __restrict__ out)
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-k_bfs_brick_seed(int* __restrict__ dist, int cx, int cy, int cz, int nbx, int nby, int* __restrict__ list0, int* __restrict__ counts, int tag_word)
+k_bfs_brick_seed(int* __restrict__ dist, int cx, int cy, int cz, int nbx, int nby, int nbz, int* __restrict__ list0, int* __restrict__ counts, int tag_word)
 {
     // counts: 3 sets x SMPLX_BFS_SHARDS counters, 32 ints apart
     if (blockIdx.x == 0) {
@@ -2335,6 +2355,8 @@ k_bfs_brick_seed(int* __restrict__ dist, int cx, int cy, int cz, int nbx, int nb
         if (t == 0) {
             const int brick = ((cz >> 3) * nby + (cy >> 3)) * nbx + (cx >> 3);
             bfs_record_store_cell(dist + (size_t)brick * SMPLX_BFS_REC, cx & 7, cy & 7, cz & 7, tag_word);   // distance 0; overwrites a wall at the goal cell, as bfs3d.cpp:178 does
+            const int lx = cx & 7, ly = cy & 7, lz = cz & 7;
+            if ((lx == 0 || lx == 7) && (ly == 0 || ly == 7) && (lz == 0 || lz == 7)) bfs_push_corner(dist, cx >> 3, cy >> 3, cz >> 3, nbx, nby, nbz, lx, ly, lz, tag_word);
             list0[0] = brick;      // sub-list 0 of list 0
             counts[0] = 1;
         }
@@ -2549,7 +2571,10 @@ k_bfs_brick_wave(int* __restrict__ dist, int nbx, int nby, int nbz,
             if (y_hi) rec[SMPLX_BFS_FACES + 3 * 64 + z * 8 + tx] = val;
             if (z == 0) rec[SMPLX_BFS_FACES + 4 * 64 + ty * 8 + tx] = val;
             if (z == SMPLX_BRICK - 1) rec[SMPLX_BFS_FACES + 5 * 64 + ty * 8 + tx] = val;
-            if ((x_lo || x_hi) && (y_lo || y_hi)) rec[SMPLX_BFS_EDGES + ((y_hi ? 2 : 0) + (x_hi ? 1 : 0)) * 8 + z] = val;
+            if ((x_lo || x_hi) && (y_lo || y_hi)) {
+                rec[SMPLX_BFS_EDGES + ((y_hi ? 2 : 0) + (x_hi ? 1 : 0)) * 8 + z] = val;
+                if (z == 0 || z == SMPLX_BRICK - 1) bfs_push_corner(dist, bxx, byy, bzz, nbx, nby, nbz, tx, ty, z, val);
+            }
         }
         // ---- Which neighbour bricks have to look again: only one that CAN improve -- a cell c' of it (this brick's halo holds
         // its value h as of the load; it can only have become smaller since) next to a cell c of this brick with h > d(c) + 1.
