@@ -15,6 +15,7 @@ typedef unsigned long size_t;
 #define SMPLX_MAX_VARS 16
 #define SMPLX_MAX_JOINTS 40
 #define SMPLX_MAX_NODES 128
+#define SMPLX_STACK_BYTES 16      // per-thread traversal stack of the sphere-tree walks (LDS): the model compiler refuses deeper trees
 #define SMPLX_MAX_TREES 24
 #define SMPLX_MAX_PAIRS 160
 #define SMPLX_MAX_PRIMS 64

@@ -9,7 +9,6 @@
 #include "device_types.h"
 
 #define SMPLX_BLOCK 128          // 2 waves; per-thread LDS scratch keeps ~4 blocks per CU resident
-#define SMPLX_STACK_BYTES 32
 #define SMPLX_SEARCH_STATIC_LDS (39 * 1024)   // static LDS of k_search (2 x ExpandLds + SearchLds + header and primitives copies), an upper bound
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 

@@ -497,6 +497,20 @@ bool compile_robot_text(const char* text, HostModel& m)
         D.pair_first[D.ntrees] = n;
     }
 
+    // The traversal stacks of the kernels (kernels.hip check_tree / resolve_root: one byte per level below the root;
+    // check_pair_full: two bytes per split of either tree) live in SMPLX_STACK_BYTES bytes of LDS per thread
+    {
+        std::function<int(int)> depth = [&](int n) { return D.nodes[n].left < 0 ? 0 : 1 + std::max(depth(D.nodes[n].left), depth(D.nodes[n].right)); };
+        std::vector<int> d(D.ntrees, 0);
+        for (int t = 0; t < D.ntrees; ++t) {
+            d[t] = depth(D.tree_first[t + 1] - 1);
+            if (d[t] > SMPLX_STACK_BYTES) return fail("a sphere tree is too deep for the traversal stack (SMPLX_STACK_BYTES)");
+        }
+        for (int k = 0; k < D.npairs; ++k)
+            if (2 * (d[D.pair_a[k]] + d[D.pair_b[k]]) > SMPLX_STACK_BYTES)
+                return fail("the sphere trees of a checked link pair are too deep for the traversal stack (SMPLX_STACK_BYTES)");
+    }
+
     // chain to the planning link
     int l = link_index(m.planning_link);
     if (l < 0) return fail("planning link unknown: " + m.planning_link);
