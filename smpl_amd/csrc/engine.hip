@@ -217,6 +217,7 @@ struct smplx_space {
     int device = 0;   // HIP device the handle lives on (worker threads select it explicitly)
     int N = 0, M = 0;
     size_t lds_bytes = 0, blob_bytes = 0;
+    size_t lds_bytes_valid = 0;      // k_state_valid: in the per-robot build it keeps the saved link transforms in registers
     int lds_nroot = 0;   // root-position slots per thread in LDS: none in the per-robot build (they live in registers there)
     // BFS
     int32_t* d_bfs = nullptr;
@@ -1279,6 +1280,7 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
     }
     s->lds_nroot = s->ks.specialized ? 0 : s->model.dev.nroot;
     s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars);
+    s->lds_bytes_valid = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->ks.specialized ? 0 : s->model.dev.nslots, s->model.dev.nvars);
     if (s->lds_bytes > 160 * 1024) { smplx_space_destroy(s); return set_error(SMPLX_E_LIMIT, "model needs more LDS per block than a CU has (160 KB)"); }
     if ((e = hipEventCreateWithFlags(&s->batch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");
@@ -1425,7 +1427,7 @@ int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* 
     if ((e = s->b_flags.reserve(n))) return e;
     if ((e = s->b_lookups.reserve(n))) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, q, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
-    KLAUNCH(s, K_STATE_VALID, k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
+    KLAUNCH(s, K_STATE_VALID, k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes_valid, s->stream, s->d_space,
                        s->b_q.p, n, s->b_flags.p, s->b_lookups.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));
@@ -1437,7 +1439,7 @@ int smplx_cc_state_valid_batch(smplx_space* s, const double* q, int n, uint8_t* 
 int smplx_cc_state_valid_batch_device(smplx_space* s, const double* d_q, int n, uint8_t* d_valid, int32_t* d_lookups, void* stream)
 {
     if (!s || !d_q || !d_valid || n <= 0) return set_error(SMPLX_E_ARG, "bad argument");
-    KLAUNCH(s, K_STATE_VALID, k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, (hipStream_t)stream,
+    KLAUNCH(s, K_STATE_VALID, k_state_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes_valid, (hipStream_t)stream,
             s->d_space, d_q, n, d_valid, d_lookups);
     HIP_TRY(hipGetLastError());
     return SMPLX_OK;

@@ -419,6 +419,9 @@ struct ChainState {
     // squared cell distance the lookup returns
     double Tp[12];
     int pd2;
+    // RS (const_chain<.., true>): the saved link transforms here instead of in the thread's LDS slots -- 96 bytes of LDS per
+    // thread and slot were what held the validity kernels at three waves per SIMD
+    double S[SMPLX_MAX_SLOTS][12];
 };
 
 template <int T_, int K, int KEND>
@@ -556,7 +559,7 @@ __device__ __forceinline__ bool resolve_root(const ModelLds* __restrict__ M, con
 }
 
 // PT = the tree whose root lookup was issued at an earlier joint and has not been looked at yet (-1: none)
-template <int J, int PT>
+template <int J, int PT, bool RS = false>
 __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                             ChainState& C, int& lookups)
 {
@@ -564,7 +567,7 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J], tree = CM_TREE[J];
         if constexpr (src >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) C.T[i] = lds_d(L, L.slot_base + 12 * src + i);
+            for (int i = 0; i < 12; ++i) C.T[i] = RS ? C.S[src][i] : lds_d(L, L.slot_base + 12 * src + i);
         }
         double q = 0.0;
         if constexpr (var >= 0) q = C.q[var];
@@ -572,7 +575,7 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
         else apply_joint(&M->joints[J], q, C.T, src == SMPLX_SRC_ROOT);
         if constexpr (save >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = C.T[i];
+            for (int i = 0; i < 12; ++i) { if constexpr (RS) C.S[save][i] = C.T[i]; else lds_d(L, L.slot_base + 12 * save + i) = C.T[i]; }
         }
         // the lookup issued at the previous tree has had this joint's sincos and products to land behind
         if constexpr (PT >= 0) {
@@ -592,9 +595,9 @@ __device__ __forceinline__ bool const_chain(const ModelLds* __restrict__ M, cons
 #ifndef ABL_NO_PAIRS
             const_pairs<tree, CM_PAIR_FIRST[tree], CM_PAIR_FIRST[tree + 1]>(L, C, rp);
 #endif
-            return const_chain<J + 1, tree>(M, L, g, C, lookups);
+            return const_chain<J + 1, tree, RS>(M, L, g, C, lookups);
         } else {
-            return const_chain<J + 1, -1>(M, L, g, C, lookups);
+            return const_chain<J + 1, -1, RS>(M, L, g, C, lookups);
         }
     } else {
         if constexpr (PT >= 0) {
@@ -634,16 +637,16 @@ __device__ __forceinline__ void const_planning_chain(const ModelLds* __restrict_
 #ifdef SMPLX_CONST_MODEL
 // fk_two_links for the per-robot build: the transforms of the links at joints ja and jb, the chain walked as in
 // const_chain (same operations in the same order: identical bits), stopping behind the later of the two
-template <int J>
+template <int J, bool RS = false>
 __device__ __forceinline__ void const_two_links(const ModelLds* __restrict__ M, const ThreadLds& L, double T[12], const double* q,
-                                                int ja, int jb, int last, double Ta[12], double Tb[12])
+                                                int ja, int jb, int last, double Ta[12], double Tb[12], double (&S)[SMPLX_MAX_SLOTS][12])
 {
     if constexpr (J < CM_NJ) {
         if (J > last) return;
         constexpr int kind = CM_KIND[J], var = CM_VAR[J], src = CM_SRC[J], save = CM_SAVE[J];
         if constexpr (src >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = lds_d(L, L.slot_base + 12 * src + i);
+            for (int i = 0; i < 12; ++i) T[i] = RS ? S[src][i] : lds_d(L, L.slot_base + 12 * src + i);
         }
         double qv = 0.0;
         if constexpr (var >= 0) qv = q[var];
@@ -651,7 +654,7 @@ __device__ __forceinline__ void const_two_links(const ModelLds* __restrict__ M, 
         else apply_joint(&M->joints[J], qv, T, src == SMPLX_SRC_ROOT);
         if constexpr (save >= 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) lds_d(L, L.slot_base + 12 * save + i) = T[i];
+            for (int i = 0; i < 12; ++i) { if constexpr (RS) S[save][i] = T[i]; else lds_d(L, L.slot_base + 12 * save + i) = T[i]; }
         }
         if (J == ja) {
 #pragma unroll
@@ -661,12 +664,13 @@ __device__ __forceinline__ void const_two_links(const ModelLds* __restrict__ M, 
 #pragma unroll
             for (int i = 0; i < 12; ++i) Tb[i] = T[i];
         }
-        const_two_links<J + 1>(M, L, T, q, ja, jb, last, Ta, Tb);
+        const_two_links<J + 1, RS>(M, L, T, q, ja, jb, last, Ta, Tb, S);
     }
 }
 #endif
 
 // sphere tree vs sphere tree (self_collision_model.cpp:1093-1218); false = collision
+template <bool RS = false>
 __device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, const ThreadLds& L, const EdgeRef& e,
                                              int ta, int tb)
 {
@@ -682,7 +686,8 @@ __device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, 
 #pragma unroll
         for (int v = 0; v < CM_NV; ++v) q[v] = lds_d(L, L.q_base + v);
         const int ja = M->tree_joint[ta], jb = M->tree_joint[tb];
-        const_two_links<0>(M, L, T, q, ja, jb, ja > jb ? ja : jb, Ta, Tb);
+        double S[SMPLX_MAX_SLOTS][12];
+        const_two_links<0, RS>(M, L, T, q, ja, jb, ja > jb ? ja : jb, Ta, Tb, S);
     }
 #else
     fk_two_links(M, L, e, M->tree_joint[ta], M->tree_joint[tb], Ta, Tb);
@@ -727,6 +732,7 @@ __device__ __forceinline__ bool check_pair_full(const ModelLds* __restrict__ M, 
 // self_collision_model.cpp:407-428): group trees vs grid in chain order, then the checked
 // link pairs sphere-vs-sphere.
 // the configuration's joint values are already staged in the thread's LDS slots (stage_config or the caller itself)
+template <bool RS = false>
 __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                                     const EdgeRef& e, int& lookups)
 {
@@ -748,7 +754,7 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
         for (int v = 0; v < CM_NV; ++v) C.q[v] = lds_d(L, L.q_base + v);
         C.pair_hit = false; C.recheck_all = false; C.P = P;
         C.pd2 = 0;
-        if (!const_chain<0, -1>(M, L, g, C, lookups)) return false;
+        if (!const_chain<0, -1, RS>(M, L, g, C, lookups)) return false;
         pair_hit = C.pair_hit; recheck_all = C.recheck_all;
         const PendingPairs filled = C.P;
         P = filled;
@@ -834,18 +840,19 @@ __device__ __forceinline__ bool config_valid_staged(const ModelLds* __restrict__
             t = code & 0xFF;
         }
         const int a = ta < t ? ta : t, b = ta < t ? t : ta;
-        if (!check_pair_full(M, L, e, a, b)) pair_hit = true;
+        if (!check_pair_full<RS>(M, L, e, a, b)) pair_hit = true;
     }
     return !pair_hit;
 }
 
+template <bool RS = false>
 __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                              const EdgeRef& e, int& lookups)
 {
 #ifndef ABL_NO_FK
     stage_config(M, L, e);
 #endif
-    return config_valid_staged(M, L, g, e, lookups);
+    return config_valid_staged<RS>(M, L, g, e, lookups);
 }
 
 // CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
@@ -1108,7 +1115,7 @@ __device__ __forceinline__ ModelLds stage_model(const SmplxSpaceDev* __restrict_
 
 // model + per-thread scratch (root-position slots, saved transforms, DFS stack)
 __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__ S, unsigned char* smem, ModelLds* Mv,
-                                               int nthreads = BLOCK)
+                                               int nthreads = BLOCK, bool slots_in_lds = true)
 {
     ThreadLds L;
     *Mv = stage_model(S, smem, nthreads);
@@ -1123,8 +1130,9 @@ __device__ __forceinline__ ThreadLds setup_lds(const SmplxSpaceDev* __restrict__
 #endif
     L.root_base = 0;
     L.slot_base = 3 * nroot;
-    L.q_base = 3 * nroot + 12 * Mv->nslots;
-    const int nd = 3 * nroot + 12 * Mv->nslots + Mv->nvars;
+    const int nslots = slots_in_lds ? Mv->nslots : 0;      // (a kernel that keeps the saved transforms in registers: const_chain<.., true>)
+    L.q_base = 3 * nroot + 12 * nslots;
+    const int nd = 3 * nroot + 12 * nslots + Mv->nvars;
     L.stk = (LDS_AS unsigned char*)(L.d + nd * nthreads);
     __syncthreads();
     return L;
@@ -2126,7 +2134,12 @@ k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
 {
     extern __shared__ __align__(16) unsigned char smem[];
     ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv);
+#ifdef SMPLX_CONST_MODEL
+    constexpr bool RS = true;      // saved link transforms in registers: engine.hip sizes this kernel's LDS without the slots
+#else
+    constexpr bool RS = false;
+#endif
+    ThreadLds L = setup_lds(S, smem, &Mv, BLOCK, !RS);
     const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -2134,7 +2147,7 @@ k_state_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q,
     e.start = Q + (size_t)i * MV_NVARS(M); e.finish = e.start; e.alpha = 0.0;
     int lk = 0;
     const SmplxGridDev grid = S->grid;
-    const bool ok = config_valid(M, L, grid, e, lk);
+    const bool ok = config_valid<RS>(M, L, grid, e, lk);
     out[i] = ok ? 1 : 0;
     if (out_lookups) out_lookups[i] = lk;
 }
