@@ -217,7 +217,7 @@ struct smplx_space {
     int device = 0;   // HIP device the handle lives on (worker threads select it explicitly)
     int N = 0, M = 0;
     size_t lds_bytes = 0, blob_bytes = 0;
-    size_t lds_bytes_valid = 0;      // k_state_valid: in the per-robot build it keeps the saved link transforms in registers
+    size_t lds_bytes_valid = 0;      // k_state_valid, k_edge_valid: in the per-robot build they keep the saved link transforms in registers
     int lds_nroot = 0;   // root-position slots per thread in LDS: none in the per-robot build (they live in registers there)
     // BFS
     int32_t* d_bfs = nullptr;
@@ -1460,7 +1460,7 @@ int smplx_cc_edge_valid_batch(smplx_space* s, const double* a, const double* b, 
     if ((e = s->b_way.reserve(n))) return e;
     HIP_TRY(hipMemcpyAsync(s->b_q.p, a, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->b_q2.p, b, sizeof(double) * n * s->N, hipMemcpyHostToDevice, s->stream));
-    KLAUNCH(s, K_EDGE_VALID, k_edge_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes, s->stream, s->d_space,
+    KLAUNCH(s, K_EDGE_VALID, k_edge_valid, dim3(blocks_for(n, SMPLX_BLOCK)), dim3(SMPLX_BLOCK), s->lds_bytes_valid, s->stream, s->d_space,
                        s->b_q.p, s->b_q2.p, n, s->b_flags.p, s->b_lookups.p, s->b_way.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(valid, s->b_flags.p, n, hipMemcpyDeviceToHost, s->stream));

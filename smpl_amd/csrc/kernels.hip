@@ -857,6 +857,7 @@ __device__ __forceinline__ bool config_valid(const ModelLds* __restrict__ M, con
 
 // CollisionSpace::isStateToStateValid (collision_space.cpp:538-581).  first_wp = 1 skips waypoint 0
 // (the start configuration), whose result the caller already has.
+template <bool RS = false>
 __device__ __forceinline__ bool edge_valid(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxGridDev& g,
                                            const double* __restrict__ start, const double* __restrict__ finish,
                                            bool start_known, bool start_valid, int& lookups, int& waypoints)
@@ -889,13 +890,13 @@ __device__ __forceinline__ bool edge_valid(const ModelLds* __restrict__ M, const
             for (int j = i; j < W; j += 5) {
                 if (j == 0 && start_known) continue;
                 e.alpha = (double)j * inv;
-                if (!config_valid(M, L, g, e, lookups)) return false;
+                if (!config_valid<RS>(M, L, g, e, lookups)) return false;
             }
         }
     } else {
         for (int j = start_known ? 1 : 0; j < W; ++j) {
             e.alpha = (double)j * inv;
-            if (!config_valid(M, L, g, e, lookups)) return false;
+            if (!config_valid<RS>(M, L, g, e, lookups)) return false;
         }
     }
     return true;
@@ -2116,13 +2117,18 @@ k_edge_valid(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Aq,
 {
     extern __shared__ __align__(16) unsigned char smem[];
     ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv);
+#ifdef SMPLX_CONST_MODEL
+    constexpr bool RS = true;      // as k_state_valid below
+#else
+    constexpr bool RS = false;
+#endif
+    ThreadLds L = setup_lds(S, smem, &Mv, BLOCK, !RS);
     const ModelLds* M = &Mv;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     int lk = 0, W = 0;
     const SmplxGridDev grid = S->grid;
-    const bool ok = edge_valid(M, L, grid, Aq + (size_t)i * MV_NVARS(M), Bq + (size_t)i * MV_NVARS(M), false, true, lk, W);
+    const bool ok = edge_valid<RS>(M, L, grid, Aq + (size_t)i * MV_NVARS(M), Bq + (size_t)i * MV_NVARS(M), false, true, lk, W);
     out[i] = ok ? 1 : 0;
     if (out_lookups) out_lookups[i] = lk;
     if (out_waypoints) out_waypoints[i] = W;
