@@ -217,7 +217,7 @@ struct smplx_space {
     int device = 0;   // HIP device the handle lives on (worker threads select it explicitly)
     int N = 0, M = 0;
     size_t lds_bytes = 0, blob_bytes = 0;
-    size_t lds_bytes_valid = 0;      // k_state_valid, k_edge_valid: in the per-robot build they keep the saved link transforms in registers
+    size_t lds_bytes_valid = 0;      // k_state_valid, k_edge_valid, k_pipe_configs: in the per-robot build they keep the saved link transforms in registers
     int lds_nroot = 0;   // root-position slots per thread in LDS: none in the per-robot build (they live in registers there)
     // BFS
     int32_t* d_bfs = nullptr;
@@ -702,7 +702,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
         if (ev) (void)hipEventRecord(ev[0], stream);
         // (a smaller grid was tried -- idle blocks cost next to nothing: 22.0 us at 3 configurations per edge, 21.7 at 1.35)
         const int bc = blocks_for((long long)B + (long long)B * s->M * 3, SMPLX_BLOCK);
-        KLAUNCH(s, K_PIPE_CONFIGS, k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes, stream, s->d_space, d_q, norefs, B,
+        KLAUNCH(s, K_PIPE_CONFIGS, k_pipe_configs, dim3(bc), dim3(SMPLX_BLOCK), s->lds_bytes_valid, stream, s->d_space, d_q, norefs, B,
                            d_sq, k.edge_w, k.edge_lookups, k.edge_bad, k.state_lookups, k.state_bad, k.work, k.work_count,
                            k.capacity);
         if (ev) (void)hipEventRecord(ev[1], stream);

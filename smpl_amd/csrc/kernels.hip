@@ -1552,6 +1552,12 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
                const unsigned long long* __restrict__ work, const int* __restrict__ work_count, int capacity)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef SMPLX_CONST_MODEL
+    constexpr bool RS = true;      // saved link transforms in registers (as k_state_valid): LDS per block without the slots, which
+                                   // is what several batches in flight, or one large one, share a CU by
+#else
+    constexpr bool RS = false;
+#endif
     const int shard_cap = capacity / SMPLX_WORK_SHARDS;
     int pre[SMPLX_WORK_SHARDS + 1];   // prefix of the shard fill counts (claims beyond a shard's capacity were never written)
     pre[0] = 0;
@@ -1594,7 +1600,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             for (int v = 0; v < nv; ++v) { qs[v] = ps[v]; qf[v] = pf[v]; }
         }
         ModelLds Mv;
-        ThreadLds L = setup_lds(S, smem, &Mv);
+        ThreadLds L = setup_lds(S, smem, &Mv, BLOCK, !RS);
         const ModelLds* M = &Mv;
         const SmplxGridDev grid = S->grid;
         if (!(is_state || is_item)) return;
@@ -1611,7 +1617,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             lds_d(L, L.q_base + v) = q;
         }
 #endif
-        const bool ok = config_valid_staged(M, L, grid, e, lk);
+        const bool ok = config_valid_staged<RS>(M, L, grid, e, lk);
         if (is_state) {
             state_lookups[i] = lk;
             if (!ok) state_bad[i] = 1;
@@ -1623,7 +1629,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
     }
 #endif
     ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv);
+    ThreadLds L = setup_lds(S, smem, &Mv, BLOCK, !RS);
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const int nprims = S->actions.nprims;
@@ -1635,7 +1641,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             e.start = Q + (refs ? refs[i] : i) * nv;
             e.finish = e.start;
             e.alpha = 0.0;
-            const bool ok = config_valid(M, L, grid, e, lk);
+            const bool ok = config_valid<RS>(M, L, grid, e, lk);
             state_lookups[i] = lk;
             if (!ok) state_bad[i] = 1;
         } else {
@@ -1652,7 +1658,7 @@ k_pipe_configs(const SmplxSpaceDev* __restrict__ S, const double* __restrict__ Q
             e.start = Q + (refs ? refs[si] : (int64_t)si) * nv;
             e.finish = out_q + edge * nv;
             e.alpha = (double)wp * (1.0 / (double)(W - 1));
-            const bool ok = config_valid(M, L, grid, e, lk);
+            const bool ok = config_valid<RS>(M, L, grid, e, lk);
             atomicAdd(&edge_lookups[edge], lk);
             if (!ok) edge_bad[edge] = 1;
         }
