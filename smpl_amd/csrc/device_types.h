@@ -15,7 +15,10 @@ typedef unsigned long size_t;
 #define SMPLX_MAX_VARS 16
 #define SMPLX_MAX_JOINTS 40
 #define SMPLX_MAX_NODES 128
-#define SMPLX_STACK_BYTES 16      // per-thread traversal stack of the sphere-tree walks (LDS): the model compiler refuses deeper trees
+// per-thread traversal stack of the sphere-tree walks (LDS), in bytes: what the model's trees need (SmplxModelDev::stack_bytes,
+// worked out by the model compiler), at least MIN; a model that needs more than MAX is refused
+#define SMPLX_STACK_MIN 16
+#define SMPLX_STACK_MAX 64
 #define SMPLX_MAX_TREES 24
 #define SMPLX_MAX_PAIRS 160
 #define SMPLX_MAX_PRIMS 64
@@ -60,6 +63,7 @@ struct SmplxNode {           // sphere-tree node; trees are stored post-order, r
 
 struct alignas(16) SmplxModelDev {
     int32_t njoints, nvars, ntrees, nnodes, npairs, nslots, nchain, nroot;   // nroot: LDS root-position slots
+    int32_t stack_bytes, pad_[3];             // traversal stack per thread (SMPLX_STACK_MIN .. MAX)
     SmplxJoint joints[SMPLX_MAX_JOINTS];
     SmplxNode nodes[SMPLX_MAX_NODES];
     int32_t tree_first[SMPLX_MAX_TREES + 1];
@@ -173,7 +177,7 @@ static_assert(sizeof(SmplxModelDev) % 16 == 0 && sizeof(SmplxJoint) % 16 == 0 &&
 // (counts, then byte offsets of the segments) followed by 16-byte aligned segments.
 enum { SMPLX_BH_NJOINTS = 0, SMPLX_BH_NVARS, SMPLX_BH_NTREES, SMPLX_BH_NNODES, SMPLX_BH_NPAIRS, SMPLX_BH_NSLOTS,
        SMPLX_BH_NROOT, SMPLX_BH_BYTES, SMPLX_BH_OFF_JOINTS, SMPLX_BH_OFF_NODES, SMPLX_BH_OFF_INTS, SMPLX_BH_OFF_VARD,
-       SMPLX_BH_OFF_VARI, SMPLX_BH_WORDS = 16 };
+       SMPLX_BH_OFF_VARI, SMPLX_BH_STACK, SMPLX_BH_WORDS = 16 };
 #define SMPLX_MAX_BLOB_BYTES (64 + SMPLX_MAX_JOINTS * 144 + SMPLX_MAX_NODES * 48 + 4096)
 
 struct SmplxSearchDev;

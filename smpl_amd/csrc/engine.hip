@@ -640,7 +640,7 @@ struct ZeroCopy {
 bool small_kernel_fits(const smplx_space* s, int B)
 {
     const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes, small_block);
     return !s->fused_mode && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 && s->work_list_items == 0 &&
            s->pipeline_left == 0;
 }
@@ -665,7 +665,7 @@ int launch_expand(smplx_space* s, const double* d_q, int B, unsigned char* d_fla
     const int be = blocks_for((long long)B * s->M, SMPLX_BLOCK);
     const int64_t* norefs = nullptr;
     const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes, small_block);
     if (!force_pipeline && !s->fused_mode && !ev && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
         s->work_list_items == 0 && s->pipeline_left == 0) {
         ++s->small_launches;
@@ -863,7 +863,7 @@ int wait_event_polling(hipEvent_t ev)
 bool takes_small_kernel(const smplx_space* s, int B)
 {
     const int small_block = smplx_small_block(s->M);
-    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, small_block);
+    const size_t small_lds = smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes, small_block);
     return !s->fused_mode && s->prof_events.empty() && B <= s->small_batch_max && small_block <= 512 && small_lds <= 150 * 1024 &&
            s->work_list_items == 0 && s->pipeline_left == 0;
 }
@@ -1279,8 +1279,8 @@ int smplx_space_create(const smplx_model* model, const smplx_grid* grid, const c
         }
     }
     s->lds_nroot = s->ks.specialized ? 0 : s->model.dev.nroot;
-    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars);
-    s->lds_bytes_valid = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->ks.specialized ? 0 : s->model.dev.nslots, s->model.dev.nvars);
+    s->lds_bytes = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes);
+    s->lds_bytes_valid = smplx_lds_bytes(s->blob_bytes, s->lds_nroot, s->ks.specialized ? 0 : s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes);
     if (s->lds_bytes > 160 * 1024) { smplx_space_destroy(s); return set_error(SMPLX_E_LIMIT, "model needs more LDS per block than a CU has (160 KB)"); }
     if ((e = hipEventCreateWithFlags(&s->batch_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void**)&s->d_space, sizeof(SmplxSpaceDev))) != hipSuccess) return bail(e, "hipMalloc space");

@@ -18,13 +18,13 @@
 static inline int smplx_small_block(int nprims) { return ((nprims * 7 + 1) + 63) / 64 * 64 + 64; }
 // k_search: the same, plus a wave that works out the successors' heuristics beside the search wave where 512 threads allow it
 static inline int smplx_search_block(int nprims) { const int b = smplx_small_block(nprims); return b + 64 <= 512 ? b + 64 : b; }
-static inline size_t smplx_lds_bytes_n(size_t blob_bytes, int nroot, int nslots, int nvars, int nthreads)
+static inline size_t smplx_lds_bytes_n(size_t blob_bytes, int nroot, int nslots, int nvars, int stack_bytes, int nthreads)
 {
-    return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * nthreads + (size_t)SMPLX_STACK_BYTES * nthreads;
+    return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * nthreads + (size_t)stack_bytes * nthreads;
 }
-static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots, int nvars)
+static inline size_t smplx_lds_bytes(size_t blob_bytes, int nroot, int nslots, int nvars, int stack_bytes)
 {
-    return blob_bytes + (size_t)(3 * nroot + 12 * nslots + nvars) * 8 * SMPLX_BLOCK + (size_t)SMPLX_STACK_BYTES * SMPLX_BLOCK;
+    return smplx_lds_bytes_n(blob_bytes, nroot, nslots, nvars, stack_bytes, SMPLX_BLOCK);
 }
 
 extern "C" {

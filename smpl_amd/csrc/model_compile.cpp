@@ -498,17 +498,15 @@ bool compile_robot_text(const char* text, HostModel& m)
     }
 
     // The traversal stacks of the kernels (kernels.hip check_tree / resolve_root: one byte per level below the root;
-    // check_pair_full: two bytes per split of either tree) live in SMPLX_STACK_BYTES bytes of LDS per thread
+    // check_pair_full: two bytes per split of either tree) live in LDS, stack_bytes per thread: what this model's trees need
     {
         std::function<int(int)> depth = [&](int n) { return D.nodes[n].left < 0 ? 0 : 1 + std::max(depth(D.nodes[n].left), depth(D.nodes[n].right)); };
         std::vector<int> d(D.ntrees, 0);
-        for (int t = 0; t < D.ntrees; ++t) {
-            d[t] = depth(D.tree_first[t + 1] - 1);
-            if (d[t] > SMPLX_STACK_BYTES) return fail("a sphere tree is too deep for the traversal stack (SMPLX_STACK_BYTES)");
-        }
-        for (int k = 0; k < D.npairs; ++k)
-            if (2 * (d[D.pair_a[k]] + d[D.pair_b[k]]) > SMPLX_STACK_BYTES)
-                return fail("the sphere trees of a checked link pair are too deep for the traversal stack (SMPLX_STACK_BYTES)");
+        int need = 0;
+        for (int t = 0; t < D.ntrees; ++t) { d[t] = depth(D.tree_first[t + 1] - 1); need = std::max(need, d[t]); }
+        for (int k = 0; k < D.npairs; ++k) need = std::max(need, 2 * (d[D.pair_a[k]] + d[D.pair_b[k]]));
+        if (need > SMPLX_STACK_MAX) return fail("the sphere trees are too deep for the traversal stack (SMPLX_STACK_MAX bytes per thread)");
+        D.stack_bytes = std::max(SMPLX_STACK_MIN, (need + 7) / 8 * 8);
     }
 
     // chain to the planning link
@@ -601,6 +599,7 @@ size_t pack_model_blob(const SmplxModelDev& m, unsigned char* out, size_t cap)
     hdr[SMPLX_BH_NROOT] = m.nroot; hdr[SMPLX_BH_BYTES] = (int32_t)off;
     hdr[SMPLX_BH_OFF_JOINTS] = (int32_t)o_j; hdr[SMPLX_BH_OFF_NODES] = (int32_t)o_n; hdr[SMPLX_BH_OFF_INTS] = (int32_t)o_i;
     hdr[SMPLX_BH_OFF_VARD] = (int32_t)o_d; hdr[SMPLX_BH_OFF_VARI] = (int32_t)o_v;
+    hdr[SMPLX_BH_STACK] = m.stack_bytes;
     std::memset(out, 0, off);
     std::memcpy(out, hdr, sizeof(hdr));
     std::memcpy(out + o_j, m.joints, (size_t)m.njoints * sizeof(SmplxJoint));
@@ -657,7 +656,7 @@ std::string model_const_header(const SmplxModelDev& m)
         if (n == 0) o += "0";
         o += "};\n";
     };
-    snprintf(buf, sizeof buf, "#define CM_NJ %d\n#define CM_NT %d\n#define CM_NV %d\n", m.njoints, m.ntrees, m.nvars);
+    snprintf(buf, sizeof buf, "#define CM_NJ %d\n#define CM_NT %d\n#define CM_NV %d\n#define CM_STACK_BYTES %d\n", m.njoints, m.ntrees, m.nvars, m.stack_bytes);
     o += buf;
     ints("CM_KIND", m.njoints, [&](int i) { return m.joints[i].kind; });
     ints("CM_VAR", m.njoints, [&](int i) { return m.joints[i].var; });

@@ -432,7 +432,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
 #endif
         const int* hdr = reinterpret_cast<const int*>(S->model_blob);
         unsigned int off = (unsigned int)hdr[SMPLX_BH_BYTES] +
-                           (unsigned int)((3 * nroot_lds + 12 * Mv.nslots + Mv.nvars) * 8 + SMPLX_STACK_BYTES) * (unsigned int)book0;
+                           (unsigned int)((3 * nroot_lds + 12 * Mv.nslots + Mv.nvars) * 8 + hdr[SMPLX_BH_STACK]) * (unsigned int)book0;
         off = (off + 15u) & ~15u;
         H.lds = (LDS_AS hent_t*)((LDS_AS unsigned char*)smem + off);
         H.hbm = (SMPLX_GLOBAL_AS hent_t*)as_global(P->heap);

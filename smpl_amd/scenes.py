@@ -440,6 +440,15 @@ def config5(n: int = 512, nboxes: int = 128, seed: int = 5, res: float = 0.01) -
                   [3.0 * DEG] * 14, boxes)
 
 
+def with_extra_spheres(robot_text: str, n: int, links=("shoulder_pan_link", "forearm_link")) -> str:
+    """The robot with n more small spheres in a row on each of two links that form a checked pair: deeper sphere trees
+    (tests of the traversal-stack sizing)."""
+    lines = robot_text.split("\n")
+    i = max(k for k, l in enumerate(lines) if l.startswith("sphere "))
+    extra = [f"sphere {link} x{j}_{k} {0.02 * k:.6f} 0.0 0.0 0.02 1" for j, link in enumerate(links) for k in range(n)]
+    return "\n".join(lines[:i + 1] + extra + lines[i + 1:])
+
+
 def random_states(cfg_limits, n: int, seed: int = 12345) -> np.ndarray:
     """n joint states uniform within limits (scheme of
     sbpl_collision_checking_test/src/benchmark_cc.cpp:280-301); continuous joints in [-pi, pi]."""

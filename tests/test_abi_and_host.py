@@ -130,6 +130,13 @@ def test_model_constants_header_describes_the_chain(small_cfg):
     assert "0x1." in h.split("CM_VAR_K")[1].split("\n")[0]
 
 
+def test_traversal_stack_is_sized_by_the_models_trees(small_cfg):
+    """The sphere-tree walks of the kernels keep their stack in LDS; its size per thread comes from the model (depth of
+    the trees, twice the summed depths of a checked pair), 16 bytes at least."""
+    assert "#define CM_STACK_BYTES 16" in _const_header(small_cfg.robot_text)
+    assert "#define CM_STACK_BYTES 24" in _const_header(scenes.with_extra_spheres(small_cfg.robot_text, 14))
+
+
 @pytest.mark.parametrize("robot", ["arm7", "dual14", "mixed"])
 def test_per_robot_source_compiles_for_gfx950_with_the_helper(robot, tmp_path):
     """What smplx_space_create does on the GPU box, minus the module load: header -> smplx_rtc -> code object."""

@@ -74,6 +74,28 @@ def test_bfs_grid_over_ten_goals_in_one_space(small_cfg):
             assert not ((out >= 0) & (out < 0x7FFFFFFF)).any()
 
 
+def test_state_validity_with_deeper_sphere_trees(small_cfg):
+    """A robot whose trees need a 24-byte traversal stack (the default is 16): verdicts and lookup tallies of random states
+    and edges still equal the oracle's."""
+    import copy
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    cfg = copy.copy(small_cfg)
+    cfg.robot_text = scenes.with_extra_spheres(small_cfg.robot_text, 14)
+    o = Oracle(cfg)
+    o.set_order(chain=True)
+    s = capi.Space.from_config(cfg)
+    Q = _random_states(1500, 21)
+    ok, lk = s.state_valid_batch(Q)
+    exp = [o.state_valid(q) for q in Q]
+    assert np.array_equal(ok.astype(bool), np.array([e[0] for e in exp]))
+    assert np.array_equal(lk, np.array([e[1] for e in exp]))
+    assert 0.02 < ok.mean() < 0.98
+    o.set_goal_joint(cfg.goal, cfg.goal_tol)
+    s.set_goal_joint(cfg.goal, cfg.goal_tol)
+    _compare_expand(o, s, Q[ok.astype(bool)][:40])
+
+
 def test_sphere_positions_bitwise(ctx):
     cfg, o, s = ctx
     Q = _random_states(64, 1)
