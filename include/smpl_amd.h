@@ -337,6 +337,14 @@ int smplx_search_counters(const smplx_space* s, int64_t out[16]);
  * splits them into that many slices, each driven by its own host thread.  (BASELINE config 4: 128 queries per GPU.) */
 int smplx_plan_multi(smplx_space** spaces, int nq, const smplx_search_params* p, int32_t* path_ids, int cap,
                      smplx_search_stats* stats, double* wall_seconds, int host_threads);
+
+/* Query sharding over ranks, one process per GPU (independent queries partition over GPUs with no data-path
+ * collective; the demo's outer loop over requests, smpl_test/src/call_planner.cpp): rank r of `world` owns queries
+ * [*first, *first + *count) of a list of `total`, `per_rank` each (BASELINE config 4: 128), the last ranks possibly fewer or
+ * none.  A C or C++ caller plans its range with smplx_plan_multi on its own GPU and gathers the per-query results with
+ * whatever its job uses (MPI, RCCL: a few integers per query). */
+int smplx_shard_range(int rank, int world, int total, int per_rank, int* first, int* count);
+
 int smplx_expansion_log_size(const smplx_space* s);
 int smplx_expansion_log(const smplx_space* s, int32_t* out);
 /* ManipLattice::extractPath for a plain id path (manip_lattice.cpp:2018-2155): q[len][nvars] */

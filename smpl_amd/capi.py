@@ -20,7 +20,7 @@ _u64p = C.POINTER(C.c_uint64)
 
 # every symbol include/smpl_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "smplx_last_error", "smplx_device_count", "smplx_grid_create", "smplx_grid_destroy", "smplx_model_create",
+    "smplx_last_error", "smplx_device_count", "smplx_shard_range", "smplx_grid_create", "smplx_grid_destroy", "smplx_model_create",
     "smplx_model_destroy", "smplx_model_counts", "smplx_model_joints", "smplx_model_nodes", "smplx_model_pairs",
     "smplx_space_create", "smplx_space_destroy", "smplx_space_num_vars", "smplx_space_num_prims",
     "smplx_space_discretization", "smplx_cc_state_valid_batch", "smplx_cc_edge_valid_batch", "smplx_cc_interpolate",

@@ -1095,6 +1095,15 @@ extern "C" {
 
 const char* smplx_last_error(void) { return g_error.c_str(); }
 
+int smplx_shard_range(int rank, int world, int total, int per_rank, int* first, int* count)
+{
+    if (!first || !count || world <= 0 || rank < 0 || rank >= world || total < 0 || per_rank <= 0) return set_error(SMPLX_E_ARG, "bad shard arguments");
+    const long long f = (long long)rank * per_rank;
+    *first = (int)std::min<long long>(f, total);
+    *count = (int)std::max<long long>(0, std::min<long long>(f + per_rank, total) - *first);
+    return SMPLX_OK;
+}
+
 int smplx_device_count(void)
 {
     int n = 0;

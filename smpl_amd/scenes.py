@@ -498,8 +498,8 @@ def config4_queries(starts, goals, start_ok, goal_ok, n: int = 1024):
 def shard_range(rank: int, world: int, total: int = 1024, per_rank: int = 128):
     """Queries [first, last) of rank `rank`: 128 per GPU (BASELINE config 4); with fewer than total/per_rank ranks the
     job simply covers a prefix of the list (weak scaling: per-GPU work is fixed)."""
-    first = rank * per_rank
-    return first, min(first + per_rank, total)
+    first = min(rank * per_rank, total)
+    return first, min(rank * per_rank + per_rank, total) if rank * per_rank < total else first
 
 
 # ----------------------------------------------------------------------------

@@ -130,6 +130,21 @@ def test_model_constants_header_describes_the_chain(small_cfg):
     assert "0x1." in h.split("CM_VAR_K")[1].split("\n")[0]
 
 
+def test_shard_range_in_the_abi_matches_the_python_sharding():
+    import ctypes as C
+    L = capi.lib()
+    f, c = C.c_int(), C.c_int()
+    for world in (1, 2, 8, 9):
+        covered = []
+        for rank in range(world):
+            assert L.smplx_shard_range(rank, world, 1024, 128, C.byref(f), C.byref(c)) == 0
+            a, b = scenes.shard_range(rank, world, 1024, 128)
+            assert (f.value, f.value + c.value) == (a, b)
+            covered += list(range(a, b))
+        assert covered == list(range(min(1024, 128 * world)))
+    assert L.smplx_shard_range(3, 2, 1024, 128, C.byref(f), C.byref(c)) != 0     # rank out of range
+
+
 def test_traversal_stack_is_sized_by_the_models_trees(small_cfg):
     """The sphere-tree walks of the kernels keep their stack in LDS; its size per thread comes from the model (depth of
     the trees, twice the summed depths of a checked pair), 16 bytes at least."""
