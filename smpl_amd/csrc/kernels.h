@@ -9,7 +9,7 @@
 #include "device_types.h"
 
 #define SMPLX_BLOCK 128          // 2 waves; per-thread LDS scratch keeps ~4 blocks per CU resident
-#define SMPLX_SEARCH_STATIC_LDS (39 * 1024)   // static LDS of k_search (2 x ExpandLds + SearchLds + header and primitives copies), an upper bound
+#define SMPLX_SEARCH_STATIC_LDS (44 * 1024)   // static LDS of k_search (2 x ExpandLds + SearchLds + header and primitives copies), an upper bound
 #define SMPLX_TALLIES 6           // per-block tallies (tally_block)     // per-thread DFS stack (node indices, one byte each)
 
 // dynamic LDS bytes: the packed model, plus (collision kernels) per-thread scratch

@@ -37,6 +37,9 @@ enum { SA_EVAL = 0, SA_SKIP = 1, SA_REORDER = 2, SA_EXIT = 3 };
 struct SearchLds {
     int action;                            // the round, published before its first barrier
     int buf;                               // ... and the ExpandLds it works on
+    int seq;                               // ... and its number
+    int go;                                // = seq once the state table holds everything committed before this round's state was
+                                           //   popped: the helper wave may probe it (the search wave sets it before it joins the round's end)
     double reorder_eps;
     int reorder_size, reorder_dups;
     // ancestors of the slots the pushes of a relaxation will take, as far as they lie in HBM: level j (1 = parents) holds
@@ -53,6 +56,14 @@ typedef unsigned long long hent_t;
 __device__ __forceinline__ unsigned int hent_f(hent_t e) { return (unsigned int)e; }
 __device__ __forceinline__ int hent_id(hent_t e) { return (int)(e >> 32); }
 __device__ __forceinline__ hent_t hent_make(unsigned int f, int id) { return (hent_t)f | ((hent_t)(unsigned int)id << 32); }
+
+// what the helper wave leaves for the search wave at the end of a round: lane = primitive
+struct BookOut {
+    int limits_ok[64], wcount[64], h[64], is_goal[64];
+    unsigned int hash[64], free_slot[64];
+    int pr_id[64], dup_of[64], clash[64];
+    int ss[8][64];                         // the successor's search state as stored (sstate_load's two 16-byte words)
+};
 
 struct HeapRef {
     LDS_AS hent_t* lds;                    // entries [0, lh)
@@ -383,6 +394,53 @@ struct SearchRegs {
     long long committed_evals, gpu_evals, lookups;
 };
 
+// getOrCreateState's table side (manip_lattice.cpp:1302-1354) for the successors of one expansion, by a whole wave (lane =
+// primitive; every lane calls): hash and probe of each candidate's coordinate, the search state of a coordinate the table
+// knows, and among the unknown ones the pairs that share a coordinate (the lower primitive creates the state) or whose
+// probing ended at the same empty slot.  WithGoalFK: the planning-link FK / BFS cell / goal test of the successor is done
+// here, between the probe's loads and their use (the search wave without a helper wave); otherwise b holds them already.
+struct BookRegs { unsigned int hash; TableProbe pr; int dup_of; bool clash; };
+template <bool WithGoalFK>
+__device__ __forceinline__ void search_book_table(const ModelLds* __restrict__ M, const SmplxGridDev& grid, const SmplxBfsDev& bfs,
+                                                  const SmplxGoalDev& G, const SmplxTableDev& table, SMPLX_GLOBAL_AS SmplxSState* st,
+                                                  ExpandLds& X, int lane, int nv, bool act, BookLane& b, BookRegs& o, SmplxSState& ss)
+{
+    o.hash = 0; o.pr.id = -1; o.pr.free_slot = 0; o.dup_of = -1; o.clash = false;
+    if (act && b.limits_ok) {
+        // getHashEntry (manip_lattice.cpp:1302-1316): the home slot's loads travel behind the planning-link FK; a coordinate the
+        // table knows has its search state requested at once (it lands behind the waypoint lanes)
+        o.hash = coord_hash_lds((const LDS_AS int*)X.coord[lane], nv);
+        TableProbeLoads ld = table_probe_start(table, nv, o.hash);
+        if constexpr (WithGoalFK) expand_book_goal(M, grid, bfs, G, X, lane, b);
+        o.pr = table_probe_finish(table, ld, (const LDS_AS int*)X.coord[lane], nv);
+        if (o.pr.id >= 0 && (!WithGoalFK || !b.is_goal)) ss = sstate_load(&st[o.pr.id]);   // (a goal successor takes the goal's state)
+    }
+    const bool c_unknown = act && b.limits_ok && o.pr.id < 0;
+    {
+        unsigned long long members = __ballot(c_unknown);
+        while (members) {                                // uniform
+            const int j = __ffsll((long long)members) - 1;
+            members &= members - 1;
+            const unsigned int hj = wave_rlu(o.hash, j);
+            if (j < lane && c_unknown && o.dup_of < 0 && hj == o.hash) {
+                bool same = true;
+                for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
+                if (same) o.dup_of = j;
+            }
+        }
+    }
+    {
+        const bool mine = c_unknown && o.dup_of < 0;
+        unsigned long long members = __ballot(mine);
+        while (members) {
+            const int j = __ffsll((long long)members) - 1;
+            members &= members - 1;
+            const unsigned int fj = wave_rlu(o.pr.free_slot, j);
+            if (j < lane && mine && fj == o.pr.free_slot) o.clash = true;
+        }
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(512)
 k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, int* __restrict__ status_out)
 {
@@ -391,8 +449,9 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     __shared__ SearchLds W;
     __shared__ SmplxSearchDev Ph;                // the query's header as the launch found it: pointers, capacities, parameters
     __shared__ SmplxGoalDev Gh;                  // ... and the goal
+    __shared__ BookOut Bo;                       // helper wave -> search wave, once per round
     __shared__ SmplxActionsDev Ah;               // the primitives: read by the search wave several times per expansion, each read a round trip to L2 otherwise
-    static_assert(2 * sizeof(ExpandLds) + sizeof(SearchLds) + sizeof(SmplxSearchDev) + sizeof(SmplxActionsDev) + sizeof(SmplxGoalDev) <= SMPLX_SEARCH_STATIC_LDS, "engine.hip budgets this much static LDS");
+    static_assert(2 * sizeof(ExpandLds) + sizeof(SearchLds) + sizeof(SmplxSearchDev) + sizeof(SmplxActionsDev) + sizeof(SmplxGoalDev) + sizeof(BookOut) <= SMPLX_SEARCH_STATIC_LDS, "engine.hip budgets this much static LDS");
     const SmplxSpaceDev* Sq = stab[blockIdx.x];
     const SmplxSpaceDev* S = stab[0];            // scene, robot and primitives are shared by the queries of a launch
     SmplxSearchDev* const Pd = Sq->search;
@@ -407,7 +466,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     for (int i = t; i < (int)(sizeof(SmplxSearchDev) / 4); i += blockDim.x) ((int*)&Ph)[i] = ((const int*)Pd)[i];
     for (int i = t; i < (int)(sizeof(SmplxActionsDev) / 4); i += blockDim.x) ((int*)&Ah)[i] = ((const int*)&S->actions)[i];
     for (int i = t; i < (int)(sizeof(SmplxGoalDev) / 4); i += blockDim.x) ((int*)&Gh)[i] = ((const int*)&Sq->goal)[i];
-    if (t == 0) { W.action = SA_SKIP; W.buf = 0; W.ac_nlev = 0; }
+    if (t == 0) { W.action = SA_SKIP; W.buf = 0; W.seq = 0; W.go = 0; W.ac_nlev = 0; }
     __syncthreads();
     const SmplxSearchDev* const P = &Ph;         // read-only view; what changes lives in the search wave and goes back to Pd at the end
     const SmplxActionsDev& A = Ah;
@@ -446,9 +505,9 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     __syncthreads();
 
     // The wave behind the search wave, where the block has one (smplx_search_block): between the two barriers of a round it
-    // works out, for every primitive with an action, what the search wave needs of the successor beyond its coordinate --
-    // the heuristic (planning-link FK + BFS cell, ~3 us of dependent arithmetic for a lone wave) and the goal test -- and
-    // leaves them in X.h / X.flags.  The search wave's own work per expansion is what bounds the kernel.
+    // does the bookkeeping of the round's successors that does not touch OPEN -- coordinates, heuristic (planning-link FK + BFS
+    // cell), goal test, the state table's side of getOrCreateState -- and leaves it in Bo for the search wave, whose own
+    // sequential work per expansion (pop, commit, relax) is what bounds the kernel.
     const int help0 = book0 + 64;
     const bool has_helper = (int)blockDim.x > help0;
     if (t < book0 || t >= help0) {
@@ -461,14 +520,29 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 ExpandLds& Xr = Xb[W.buf];
                 if (t < book0) expand_config_lane(M, L, A, G, grid, Xr, t, ncfg);
                 else {
+                    // lane p = primitive p, as in the search wave.  First what needs no table: coordinate, planning-link FK, BFS
+                    // cell, goal test.  Then -- once the search wave says the table holds everything committed before this round's
+                    // state was popped (W.go) -- hash, probe, the known successor's search state, duplicates among the new ones.
                     const int p = t - help0;
-                    if (p < nprims && Xr.lookups[p] != 0) {           // (lookups[p]: the search wave's "primitive p has an action here")
-                        BookLane r;
-                        expand_book_coords(M, Xr, p, r);             // (the search wave writes the same coordinates)
+                    const bool act = p < nprims && Xr.lookups[p] != 0;   // (lookups[p]: the search wave's "primitive p has an action here")
+                    BookLane r;
+                    r.limits_ok = false; r.W = 0; r.h = 0; r.is_goal = 0;
+                    if (act) {
+                        expand_book_coords(M, Xr, p, r);
                         expand_book_goal(M, grid, bfs, G, Xr, p, r);
-                        Xr.h[p] = r.h;
-                        Xr.flags[p] = r.is_goal;
                     }
+                    const int my_round = W.seq;
+                    while (__atomic_load_n(&W.go, __ATOMIC_RELAXED) != my_round) __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    BookRegs o;
+                    SmplxSState ss;
+                    ss.g = ss.h = ss.f = ss.eg = 0; ss.bp = -1; ss.heap_index = 0; ss.iteration_closed = 0; ss.call_number = 0; ss.flags = 0;
+                    search_book_table<false>(M, grid, bfs, G, table, as_global(P->st), Xr, p, nv, act, r, o, ss);
+                    Bo.limits_ok[p] = r.limits_ok ? 1 : 0; Bo.wcount[p] = r.W; Bo.h[p] = r.h; Bo.is_goal[p] = r.is_goal;
+                    Bo.hash[p] = o.hash; Bo.free_slot[p] = o.pr.free_slot; Bo.pr_id[p] = o.pr.id; Bo.dup_of[p] = o.dup_of; Bo.clash[p] = o.clash ? 1 : 0;
+                    Bo.ss[0][p] = (int)ss.g; Bo.ss[1][p] = (int)ss.h; Bo.ss[2][p] = (int)ss.f; Bo.ss[3][p] = (int)ss.eg;
+                    Bo.ss[4][p] = ss.bp; Bo.ss[5][p] = ss.heap_index;
+                    Bo.ss[6][p] = (int)((unsigned int)ss.iteration_closed | ((unsigned int)ss.call_number << 16)); Bo.ss[7][p] = (int)ss.flags;
                 }
             }
             if (action == SA_REORDER) {
@@ -540,6 +614,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
         // guess is adopted (the round is already under way), a wrong one is waited out and dropped: results never depend
         // on it.  pend: the state whose round is open and not joined yet (-1: none), pbuf its buffer, p_act its lanes.
         int pend = -1, pbuf = 0;
+        int round_seq = 0;               // number of the last round opened (W.seq)
         bool p_act = false;
         long long spec_issued = 0, spec_hits = 0;
 
@@ -591,7 +666,11 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 action = SA_EVAL;
             }
 
-            if (action != SA_EVAL && pend >= 0) { __syncthreads(); pend = -1; }      // B of a round nobody will use
+            if (action != SA_EVAL && pend >= 0) {                                    // B of a round nobody will use
+                if (lane == 0) __atomic_store_n(&W.go, round_seq, __ATOMIC_RELAXED);
+                __syncthreads();
+                pend = -1;
+            }
             if (action == SA_EXIT) {
                 if (lane == 0) W.action = SA_EXIT;
                 __syncthreads();                                   // A
@@ -640,6 +719,8 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             // ---- pop (intrusive_heap.hpp:155-166).  The state popped is very often one the previous relaxation has just
             // stored (another lane of this wave did): those stores have landed before it is read ----
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // ... and so has everything the previous step committed: the helper wave of an open round may read the table now
+            if (pend >= 0 && lane == 0) __atomic_store_n(&W.go, round_seq, __ATOMIC_RELAXED);
             const SmplxSState sm = sstate_load(&as_global(P->st)[m]);           // g, h: in flight together with the loads below
             const hent_t last = hget(H, R.heap_size);
             const int off = as_global(P->done_off)[m];                          // >= 0: expanded before (a later ARA* iteration)
@@ -709,59 +790,21 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     if (act) expand_successor_values(M, A, G, X, lane);
                     if (pend >= 0) { __syncthreads(); pend = -1; }   // B of the round that guessed wrong
                     if (in) X.lookups[lane] = act ? 1 : 0;
-                    if (lane == 0) { X.goal_dist = gd; W.action = SA_EVAL; W.buf = cur; }
+                    ++round_seq;
+                    if (lane == 0) { X.goal_dist = gd; W.action = SA_EVAL; W.buf = cur; W.seq = round_seq; W.go = round_seq; }
                     __syncthreads();                                 // A
                 }
                 BookLane b;
                 b.limits_ok = false; b.W = 0; b.h = 0; b.is_goal = 0;
-                unsigned int hash = 0;
-                TableProbe pr;
-                pr.id = -1; pr.free_slot = 0;
-                if (act) {
-                    expand_book_coords(M, X, lane, b);
-                    if (b.limits_ok) {
-                        // getHashEntry (manip_lattice.cpp:1302-1316): the home slot's loads travel behind the planning-link FK;
-                        // a coordinate the table knows has its search state requested at once (it lands behind the waypoint lanes)
-                        hash = coord_hash_lds((const LDS_AS int*)X.coord[lane], nv);
-                        TableProbeLoads ld = table_probe_start(table, nv, hash);
-                        if (!has_helper) expand_book_goal(M, grid, bfs, G, X, lane, b);
-                        pr = table_probe_finish(table, ld, (const LDS_AS int*)X.coord[lane], nv);
-                        if (pr.id >= 0 && (has_helper || !b.is_goal)) ss = sstate_load(&as_global(P->st)[pr.id]);   // (a goal successor takes the goal's state below)
-                    }
+                BookRegs bk;
+                bk.hash = 0; bk.pr.id = -1; bk.pr.free_slot = 0; bk.dup_of = -1; bk.clash = false;
+                if (!has_helper) {
+                    // While the waypoint lanes work: everything of getOrCreateState that does not need their verdict
+                    if (act) expand_book_coords(M, X, lane, b);
+                    search_book_table<true>(M, grid, bfs, G, table, as_global(P->st), X, lane, nv, act, b, bk, ss);
                 }
                 const SmplxSState goal_ss = sstate_load(&as_global(P->st)[0]);   // (a goal successor relaxes the goal state)
-                // While the waypoint lanes work: everything of getOrCreateState that does not need their verdict.  Among the
-                // CANDIDATES (edges within limits) -- two with the same unknown coordinate (the lower primitive creates the
-                // state), two whose probing ended at the same empty slot -- and the heap's ancestors for the pushes to come.
-                const bool cand = act && b.limits_ok;
-                const bool c_unknown = cand && pr.id < 0;
-                auto find_dups = [&](bool mine, unsigned long long members) {
-                    int d = -1;
-                    while (members) {                                // uniform
-                        const int j = __ffsll((long long)members) - 1;
-                        members &= members - 1;
-                        const unsigned int hj = wave_rlu(hash, j);
-                        if (j < lane && mine && d < 0 && hj == hash) {
-                            bool same = true;
-                            for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
-                            if (same) d = j;
-                        }
-                    }
-                    return d;
-                };
-                auto find_clash = [&](bool mine, unsigned long long members) {
-                    bool c = false;
-                    while (members) {
-                        const int j = __ffsll((long long)members) - 1;
-                        members &= members - 1;
-                        const unsigned int fj = wave_rlu(pr.free_slot, j);
-                        if (j < lane && mine && fj == pr.free_slot) c = true;
-                    }
-                    return c;
-                };
-                int dup_of = find_dups(c_unknown, __ballot(c_unknown));
-                bool clash = find_clash(c_unknown && dup_of < 0, __ballot(c_unknown && dup_of < 0));
-                ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, __popcll(__ballot(cand)));
+                ac_complete = ancestor_cache_fill(H, W, lane, R.heap_size, __popcll(__ballot(act)));       // (an upper bound of the pushes to come)
                 // ---- while the waypoint lanes finish: the round of the most likely next state, the top of OPEN, is got ready in
                 // the other buffer (its successors' joint values), so that it can be opened the moment this round closes ----
                 const int nxt = cur ^ 1;
@@ -790,14 +833,29 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 }
                 __syncthreads();                                     // B: the waypoint verdicts have landed
                 SK_TICK(2);
-                if (has_helper && cand) { b.h = X.h[lane]; b.is_goal = X.flags[lane]; }
+                if (has_helper && in) {
+                    b.limits_ok = Bo.limits_ok[lane] != 0; b.W = Bo.wcount[lane]; b.h = Bo.h[lane]; b.is_goal = Bo.is_goal[lane];
+                    bk.hash = Bo.hash[lane]; bk.pr.free_slot = Bo.free_slot[lane]; bk.pr.id = Bo.pr_id[lane];
+                    bk.dup_of = Bo.dup_of[lane]; bk.clash = Bo.clash[lane] != 0;
+                    ss.g = (unsigned int)Bo.ss[0][lane]; ss.h = (unsigned int)Bo.ss[1][lane]; ss.f = (unsigned int)Bo.ss[2][lane];
+                    ss.eg = (unsigned int)Bo.ss[3][lane]; ss.bp = Bo.ss[4][lane]; ss.heap_index = Bo.ss[5][lane];
+                    const unsigned int itc = (unsigned int)Bo.ss[6][lane];
+                    ss.iteration_closed = (unsigned short)(itc & 0xFFFFu); ss.call_number = (unsigned short)(itc >> 16);
+                    ss.flags = (unsigned int)Bo.ss[7][lane];
+                }
+                const bool cand = act && b.limits_ok;
+                unsigned int hash = bk.hash;
+                TableProbe pr = bk.pr;
+                int dup_of = bk.dup_of;
+                bool clash = bk.clash;
                 {
                     // No edge that could create a state has a key below the top's (whatever the verdicts say): the next pop
                     // returns that top, and its round opens at once.  Otherwise the guess waits for the verdicts (below).
                     const bool maybe_new = cand && pr.id < 0 && !b.is_goal;
                     const unsigned int fj = maybe_new ? search_key(R.curr_eps, eg + (unsigned int)A.cost[lane], (unsigned int)b.h) : 0xFFFFFFFFu;
                     if (top_ready && __ballot(maybe_new && fj < top_f) == 0ull) {
-                        if (lane == 0) { W.action = SA_EVAL; W.buf = nxt; }
+                        ++round_seq;
+                        if (lane == 0) { W.action = SA_EVAL; W.buf = nxt; W.seq = round_seq; }
                         __syncthreads();                             // A of the guessed round
                         pend = top_id;
                         pbuf = nxt;
@@ -818,8 +876,27 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                     // among the valid successors only
                     const bool root_valid = __shfl((int)valid, dup_of >= 0 ? dup_of : lane) != 0;
                     if (__ballot(unknown && dup_of >= 0 && !root_valid)) {
-                        dup_of = find_dups(unknown, __ballot(unknown));
-                        clash = find_clash(unknown && dup_of < 0, __ballot(unknown && dup_of < 0));
+                        dup_of = -1;
+                        unsigned long long members = __ballot(unknown);
+                        while (members) {                            // uniform
+                            const int j = __ffsll((long long)members) - 1;
+                            members &= members - 1;
+                            const unsigned int hj = wave_rlu(hash, j);
+                            if (j < lane && unknown && dup_of < 0 && hj == hash) {
+                                bool same = true;
+                                for (int v = 0; v < nv; ++v) same = same && X.coord[j][v] == X.coord[lane][v];
+                                if (same) dup_of = j;
+                            }
+                        }
+                        const bool mine = unknown && dup_of < 0;
+                        clash = false;
+                        members = __ballot(mine);
+                        while (members) {
+                            const int j = __ffsll((long long)members) - 1;
+                            members &= members - 1;
+                            const unsigned int fj = wave_rlu(pr.free_slot, j);
+                            if (j < lane && mine && fj == pr.free_slot) clash = true;
+                        }
                     }
                 }
                 const bool is_new = unknown && dup_of < 0;
@@ -895,7 +972,8 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         p_act = in && prim_has_action(A, G, lane) && mprim_active(A, gd2, A.type[lane]);
                         if (p_act) expand_successor_values(M, A, G, Y, lane);
                         if (in) Y.lookups[lane] = p_act ? 1 : 0;
-                        if (lane == 0) { Y.goal_dist = gd2; W.action = SA_EVAL; W.buf = nxt; }
+                        ++round_seq;
+                        if (lane == 0) { Y.goal_dist = gd2; W.action = SA_EVAL; W.buf = nxt; W.seq = round_seq; }
                         __syncthreads();                             // A of the guessed round
                         pend = guess_succ ? wave_rl(sid, jbest) : top_id;
                         pbuf = nxt;
