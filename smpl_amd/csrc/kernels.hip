@@ -1923,6 +1923,7 @@ __device__ __forceinline__ int expand_waypoint_count(const ModelLds* __restrict_
 
 // config lane c of the block: c < ncfg - 1: lane (p, slot) checks waypoints slot+1, slot+8, ... of edge p (an edge longer
 // than 7 waypoints wraps around its lanes); c == ncfg - 1: the state itself (waypoint 0 of every edge)
+template <bool RS = false>
 __device__ __forceinline__ void expand_config_lane(const ModelLds* __restrict__ M, const ThreadLds& L, const SmplxActionsDev& A,
                                                    const SmplxGoalDev& G, const SmplxGridDev& grid, ExpandLds& X, int c, int ncfg)
 {
@@ -1938,7 +1939,7 @@ __device__ __forceinline__ void expand_config_lane(const ModelLds* __restrict__ 
                     EdgeRef e;
                     e.start = parent; e.finish = sq;
                     e.alpha = (double)wp * (1.0 / (double)(Wc - 1));
-                    const bool ok = config_valid(M, L, grid, e, my_lk);
+                    const bool ok = config_valid<RS>(M, L, grid, e, my_lk);
                     my_bad = ok ? 0 : 1;
                 }
                 if (my_bad) atomicOr(&X.edge_bad[p], 1);
@@ -1949,7 +1950,7 @@ __device__ __forceinline__ void expand_config_lane(const ModelLds* __restrict__ 
         EdgeRef e;
         e.start = parent; e.finish = parent; e.alpha = 0.0;
         int lk = 0;
-        const bool ok = config_valid(M, L, grid, e, lk);
+        const bool ok = config_valid<RS>(M, L, grid, e, lk);
         if (!ok) atomicOr(&X.state_bad, 1);
         if (lk) atomicAdd(&X.state_lookups, lk);
     }

@@ -48,7 +48,7 @@ int search_heap_cache_entries(const smplx_space* s, size_t* dynamic_bytes)
     const int block = smplx_search_block(s->M);
     if (block > 512 || s->M > 64) return 0;
     const int config_threads = smplx_small_block(s->M) - 64;      // per-thread scratch: the config waves only (k_search)
-    const size_t base = (smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes, config_threads) + 15) / 16 * 16;
+    const size_t base = (smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->ks.specialized ? 0 : s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes, config_threads) + 15) / 16 * 16;
     const size_t limit = 160 * 1024 - SMPLX_SEARCH_STATIC_LDS;
     if (base + 64 * sizeof(SmplxHeapEntry) > limit) return 0;
     size_t lh = (limit - base) / sizeof(SmplxHeapEntry);

@@ -475,7 +475,12 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     const int ncfg = nprims * SMPLX_SMALL_LANES + 1;          // config lanes (the last one: the state itself)
     const int book0 = (ncfg + 63) / 64 * 64;                  // first thread of the search wave
     ModelLds Mv;
-    ThreadLds L = setup_lds(S, smem, &Mv, book0);             // per-thread scratch for the config waves only (nobody else walks a chain through LDS)
+#ifdef SMPLX_CONST_MODEL
+    constexpr bool RS = true;        // the waypoint lanes keep the saved link transforms in registers (kernels.hip const_chain<.., true>)
+#else
+    constexpr bool RS = false;
+#endif
+    ThreadLds L = setup_lds(S, smem, &Mv, book0, !RS);        // per-thread scratch for the config waves only (nobody else walks a chain through LDS)
     const ModelLds* M = &Mv;
     const SmplxGridDev grid = S->grid;
     const SmplxBfsDev bfs = Sq->bfs;
@@ -491,7 +496,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
 #endif
         const int* hdr = reinterpret_cast<const int*>(S->model_blob);
         unsigned int off = (unsigned int)hdr[SMPLX_BH_BYTES] +
-                           (unsigned int)((3 * nroot_lds + 12 * Mv.nslots + Mv.nvars) * 8 + hdr[SMPLX_BH_STACK]) * (unsigned int)book0;
+                           (unsigned int)((3 * nroot_lds + 12 * (RS ? 0 : Mv.nslots) + Mv.nvars) * 8 + hdr[SMPLX_BH_STACK]) * (unsigned int)book0;
         off = (off + 15u) & ~15u;
         H.lds = (LDS_AS hent_t*)((LDS_AS unsigned char*)smem + off);
         H.hbm = (SMPLX_GLOBAL_AS hent_t*)as_global(P->heap);
@@ -518,7 +523,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             if (action == SA_EXIT) break;
             if (action == SA_EVAL) {
                 ExpandLds& Xr = Xb[W.buf];
-                if (t < book0) expand_config_lane(M, L, A, G, grid, Xr, t, ncfg);
+                if (t < book0) expand_config_lane<RS>(M, L, A, G, grid, Xr, t, ncfg);
                 else {
                     // lane p = primitive p, as in the search wave.  First what needs no table: coordinate, planning-link FK, BFS
                     // cell, goal test.  Then -- once the search wave says the table holds everything committed before this round's
