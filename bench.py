@@ -450,9 +450,15 @@ def main():
                   "collision_checks_per_s": round(n2 / (msp * 1e-3), 1), "valid_fraction": round(int(dv.sum(dtype=torch.int64).item()) / n2, 4)}
             lkp = int(dl.sum(dtype=torch.int64).item())
             kp_bytes = 4.0 * lkp + 8.0 * N * n2
+            kp_traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    kp_traffic = json.load(f)["k_state_valid_pr2"]["bytes_per_launch"] if n2 == (1 << 20) else None
+            except (OSError, KeyError, ValueError):
+                kp_traffic = None
             kp["lookups"] = lkp
             kp["roofline"] = {"bound": "hbm", "achieved": round(kp_bytes / (msp * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": round(kp_bytes / (msp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "traffic": None}
+                              "frac": round(kp_bytes / (msp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "traffic": kp_traffic}
             if Oracle is not None:
                 o = Oracle(cfg_p)
                 o.set_order(chain=True)
