@@ -347,6 +347,8 @@ int search_run(smplx_space** spaces, int nq, const smplx_search_params* p, int32
                 t_done[q] = std::chrono::duration<double>(now - t0).count();
             } else if (st == SMPLX_SS_GROW) {
                 if (int e = search_grow(spaces[q])) return e;
+            } else if (st == SMPLX_SS_ERROR) {
+                return set_error(SMPLX_E_HIP, "device search: a workgroup gave up waiting for its own search wave (internal error)");
             } else if (st != SMPLX_SS_RUNNING) {
                 return set_error(SMPLX_E_HIP, "device search: workgroup left no status (kernel fault?)");
             }

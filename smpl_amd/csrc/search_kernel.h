@@ -38,6 +38,7 @@ struct SearchLds {
     int action;                            // the round, published before its first barrier
     int buf;                               // ... and the ExpandLds it works on
     int seq;                               // ... and its number
+    int helper_gave_up;                    // the helper wave's wait for `go` ran out (never seen; turns into SMPLX_SS_ERROR)
     int go;                                // = seq once the state table holds everything committed before this round's state was
                                            //   popped: the helper wave may probe it (the search wave sets it before it joins the round's end)
     double reorder_eps;
@@ -466,7 +467,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
     for (int i = t; i < (int)(sizeof(SmplxSearchDev) / 4); i += blockDim.x) ((int*)&Ph)[i] = ((const int*)Pd)[i];
     for (int i = t; i < (int)(sizeof(SmplxActionsDev) / 4); i += blockDim.x) ((int*)&Ah)[i] = ((const int*)&S->actions)[i];
     for (int i = t; i < (int)(sizeof(SmplxGoalDev) / 4); i += blockDim.x) ((int*)&Gh)[i] = ((const int*)&Sq->goal)[i];
-    if (t == 0) { W.action = SA_SKIP; W.buf = 0; W.seq = 0; W.go = 0; W.ac_nlev = 0; }
+    if (t == 0) { W.action = SA_SKIP; W.buf = 0; W.seq = 0; W.go = 0; W.helper_gave_up = 0; W.ac_nlev = 0; }
     __syncthreads();
     const SmplxSearchDev* const P = &Ph;         // read-only view; what changes lives in the search wave and goes back to Pd at the end
     const SmplxActionsDev& A = Ah;
@@ -537,7 +538,12 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                         expand_book_goal(M, grid, bfs, G, Xr, p, r);
                     }
                     const int my_round = W.seq;
-                    while (__atomic_load_n(&W.go, __ATOMIC_RELAXED) != my_round) __builtin_amdgcn_s_sleep(2);
+                    // (bounded: ~a second; the search wave sets go before it joins the round's end on every path, so the bound is
+                    // never met -- it is there so that no wave of this kernel can wait for ever)
+                    for (int spins = 0; __atomic_load_n(&W.go, __ATOMIC_RELAXED) != my_round; ++spins) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (spins > (1 << 24)) { W.helper_gave_up = 1; break; }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     BookRegs o;
                     SmplxSState ss;
@@ -838,6 +844,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 }
                 __syncthreads();                                     // B: the waypoint verdicts have landed
                 SK_TICK(2);
+                if (has_helper && W.helper_gave_up) R.steps_left = 0;      // leave at the next selection; the status says why (below)
                 if (has_helper && in) {
                     b.limits_ok = Bo.limits_ok[lane] != 0; b.W = Bo.wcount[lane]; b.h = Bo.h[lane]; b.is_goal = Bo.is_goal[lane];
                     bk.hash = Bo.hash[lane]; bk.pr.free_slot = Bo.free_slot[lane]; bk.pr.id = Bo.pr_id[lane];
@@ -1103,6 +1110,7 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
                 }
                 R.phase = 4;
             }
+            if (W.helper_gave_up) R.status = SMPLX_SS_ERROR;
             Pd->solved = solved; Pd->cost = cost; Pd->n_path = n_path;
             Pd->curr_eps = R.curr_eps; Pd->satisfied_eps = R.satisfied_eps;
             Pd->heap_size = R.heap_size; Pd->nstates = R.nstates; Pd->n_incons = R.n_incons; Pd->n_log = R.n_log; Pd->n_succ = R.n_succ;
