@@ -473,6 +473,11 @@ class Space:
                  "device_states", "heap_cache_entries", "spec_rounds", "spec_hits"]
         return {n: int(out[i]) for i, n in enumerate(names)}
 
+    def set_search_helper(self, on):
+        """Test hook (csrc/test_hooks.h): run the device search with (default) or without its helper wave."""
+        lib().smplx_test_set_search_helper.argtypes = [C.c_void_p, C.c_int]
+        _chk(lib().smplx_test_set_search_helper(self.h, 1 if on else 0))
+
     def set_search_capacity(self, states):
         """Test hook (csrc/test_hooks.h): first capacity of the device search's buffers."""
         lib().smplx_test_set_search_capacity.argtypes = [C.c_void_p, C.c_int]

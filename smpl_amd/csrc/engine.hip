@@ -204,6 +204,7 @@ struct DevSearch {
     int64_t grows = 0, searches = 0, ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int dup_pushes = 0;
     int test_capacity = 0;               // test hook: first capacity in states
+    bool test_no_helper = false;         // test hook: launch k_search without its helper wave
 };
 
 struct smplx_space {
@@ -1359,6 +1360,13 @@ int smplx_test_set_work_list_items(smplx_space* s, int items)
 {
     if (!s || items < 0) return set_error(SMPLX_E_ARG, "bad argument");
     s->work_list_items = items / 8 * 8;
+    return SMPLX_OK;
+}
+
+int smplx_test_set_search_helper(smplx_space* s, int on)
+{
+    if (!s) return set_error(SMPLX_E_ARG, "null space");
+    s->ds.test_no_helper = on == 0;
     return SMPLX_OK;
 }
 

@@ -45,7 +45,7 @@ inline void search_carve(unsigned char* base, const SearchCaps& c, int N, SmplxS
 // heap-cache entries that fit (0 = the kernel does not fit this robot: the host-driven search serves it).
 int search_heap_cache_entries(const smplx_space* s, size_t* dynamic_bytes)
 {
-    const int block = smplx_search_block(s->M);
+    const int block = s->ds.test_no_helper ? smplx_small_block(s->M) : smplx_search_block(s->M);
     if (block > 512 || s->M > 64) return 0;
     const int config_threads = smplx_small_block(s->M) - 64;      // per-thread scratch: the config waves only (k_search)
     const size_t base = (smplx_lds_bytes_n(s->blob_bytes, s->lds_nroot, s->ks.specialized ? 0 : s->model.dev.nslots, s->model.dev.nvars, s->model.dev.stack_bytes, config_threads) + 15) / 16 * 16;
@@ -326,7 +326,7 @@ int search_run(smplx_space** spaces, int nq, const smplx_search_params* p, int32
     if (int e = status.reserve((size_t)nq)) return e;
     size_t lds = 0;
     const int lh = search_heap_cache_entries(lead, &lds);
-    const int block = smplx_search_block(lead->M);
+    const int block = lead->ds.test_no_helper ? smplx_small_block(lead->M) : smplx_search_block(lead->M);
     int max_steps = 8192;
     std::vector<char> done(nq, 0);
     int remaining = nq;

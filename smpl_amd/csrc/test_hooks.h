@@ -22,6 +22,10 @@ int smplx_test_heap_ops(const int32_t* ops, int nops, int lds_entries, int32_t* 
  * (SMPLX_SS_GROW: the host enlarges and launches again); 0 restores the default sizing. */
 int smplx_test_set_search_capacity(smplx_space* s, int states);
 
+/* on = 0: the device-resident search runs WITHOUT its helper wave (the search wave does the successors' bookkeeping inline,
+ * as it does for robots whose block would exceed 512 threads with one); 1 restores the default. */
+int smplx_test_set_search_helper(smplx_space* s, int on);
+
 #ifdef __cplusplus
 }
 #endif

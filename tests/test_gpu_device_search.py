@@ -139,10 +139,13 @@ def test_device_search_equals_the_oracle(small_cfg, goal_kind, semantics, monkey
         assert np.array_equal(h.extract_path(gh["path"]), q)
 
 
-def test_device_search_through_epsilon_steps(small_cfg, monkeypatch):
+@pytest.mark.parametrize("helper_wave", [True, False])
+def test_device_search_through_epsilon_steps(small_cfg, monkeypatch, helper_wave):
     """eps 5 -> 1 in steps of 1 on config_small with room for several improvement rounds: INCONS -> OPEN, the recomputation
     of f and the level-parallel make() of every epsilon step, re-expansions served from the committed lists.  Every
-    expansion of every round, the cost after the last finished round and its epsilon agree with the oracle."""
+    expansion of every round, the cost after the last finished round and its epsilon agree with the oracle.  Once with the
+    helper wave that does the successors' bookkeeping beside the search wave (the default where the block has room), once
+    without (test hook: the search wave does it inline, as for robots with many primitives)."""
     from oracle_binding import Oracle
     from smpl_amd import capi
     _need_gpu()
@@ -150,6 +153,7 @@ def test_device_search_through_epsilon_steps(small_cfg, monkeypatch):
     cfg = small_cfg
     o = Oracle(cfg)
     s = capi.Space.from_config(cfg, batch_states=256)
+    s.set_search_helper(helper_wave)
     o.set_goal_joint(cfg.goal, cfg.goal_tol); s.set_goal_joint(cfg.goal, cfg.goal_tol)
     assert o.set_start(cfg.start) == s.set_start(cfg.start)
     o.search_params(5.0, 1.0, 1.0, True, True, 20000, 60000)
