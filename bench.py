@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--no-shard", action="store_true")
     ap.add_argument("--no-k2", action="store_true")
+    ap.add_argument("--setup-threads", type=int, default=8, help="host threads that set goals (BFS) and starts of the shard's queries")
     ap.add_argument("--generic-kernels", action="store_true", help="skip the per-robot hiprtc build (A/B runs)")
     args = ap.parse_args()
 
@@ -628,13 +629,18 @@ def main():
         nb = args.shard_expansions
 
         def make_spaces():
+            # goal (BFS_3D::run to completion) and start of every query; eight host threads, each space on its own stream, so
+            # that the narrow passes of one BFS overlap with another's (a lone 256^3 BFS leaves most of the chip idle)
+            from concurrent.futures import ThreadPoolExecutor
             t_ = time.perf_counter()
-            sps = []
-            for a_, b_ in zip(S_mine, G_mine):
+
+            def one(ab):
                 sp = new_space(1024)
-                sp.set_goal_joint(b_, cfg.goal_tol)     # BFS_3D::run for this goal, to completion
-                sp.set_start(a_)
-                sps.append(sp)
+                sp.set_goal_joint(ab[1], cfg.goal_tol)
+                sp.set_start(ab[0])
+                return sp
+            with ThreadPoolExecutor(max_workers=args.setup_threads, initializer=lambda: torch.cuda.set_device(dev_index)) as ex:
+                sps = list(ex.map(one, zip(S_mine, G_mine)))
             torch.cuda.synchronize()
             return sps, time.perf_counter() - t_
         spaces, t_set = make_spaces()
