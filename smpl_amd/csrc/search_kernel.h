@@ -1039,7 +1039,55 @@ k_search(const SmplxSpaceDev* const* __restrict__ stab, int max_steps, int lh, i
             // flow, the state of successor j in the registers of lane j ----
             R.committed_evals += evals;
             bool dirty = false;
-            {
+            if (__ballot(valid && alias >= 0) == 0ull) {
+                // No two successors name the same state (nearly always): what expand's loop decides for a successor then depends
+                // on that successor alone, so every lane works it out for its own -- reinitSearchState, the cost test, the key --
+                // and the loop below only performs the OPEN / INCONS operations of the successors that improved, in
+                // primitive order.  (The general loop further down costs ~0.37 us per successor, improved or not.)
+                const bool fresh = valid && ss.call_number != (unsigned short)R.call_number;
+                if (fresh) {
+                    // reinitSearchState: not touched in this call (and so not in OPEN)
+                    sstate_reinit(ss, R.call_number);
+                    dirty = true;
+                    as_global(P->st)[sid].heap_index = 0;
+                }
+                const unsigned int new_cost = eg + (unsigned int)cost;
+                const bool improve = valid && new_cost < ss.g;
+                const bool reached_before = ss.g != SMPLX_INFINITECOST;
+                const bool closed_now = (unsigned int)ss.iteration_closed == ((unsigned int)R.iteration & 0xFFFFu);
+                unsigned int f = 0;
+                if (improve) {
+                    ss.g = new_cost; ss.bp = m; dirty = true;
+                    if (!closed_now) { f = search_key(R.curr_eps, new_cost, ss.h); ss.f = f; }
+                }
+                unsigned long long rest = __ballot(improve);
+                while (rest) {
+                    const int j = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int id = wave_rl(sid, j);
+                    if (wave_rl((int)closed_now, j) == 0) {
+                        const unsigned int fj = wave_rlu(f, j);
+                        const unsigned int flags_j = wave_rlu(ss.flags, j);
+                        const bool reached_j = wave_rl((int)reached_before, j) != 0;
+                        if (id == 0) R.goal_f = fj;
+                        int hi = 0;
+                        if (reached_j || !ac_complete) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // earlier sifts' stores have landed
+                        if (reached_j) hi = as_global(P->st)[id].heap_index;
+                        const hent_t e = hent_make(fj, id);
+                        if (hi != 0) {
+                            if (flags_j & 1u) heap_refresh_duplicates_wave(H, W, lane, R.heap_size, id, fj);
+                            heap_sift_up_wave(H, W, lane, hi, e, false);
+                        } else {
+                            if ((flags_j & 1u) && R.dup_pushes > 0) heap_refresh_duplicates_wave(H, W, lane, R.heap_size, id, fj);
+                            ++R.heap_size;
+                            heap_sift_up_wave(H, W, lane, R.heap_size, e, true);
+                        }
+                    } else {
+                        if (lane == 0) as_global(P->incons)[R.n_incons] = id;      // (never marked: arastar.cpp:563-565)
+                        ++R.n_incons;
+                    }
+                }
+            } else {
                 unsigned long long rest = m_succ;
                 while (rest) {
                     const int j = __ffsll((long long)rest) - 1;
