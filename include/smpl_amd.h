@@ -323,9 +323,10 @@ typedef struct smplx_search_stats {
 int smplx_plan(smplx_space* s, const smplx_search_params* p, int32_t* path_ids, int cap, smplx_search_stats* stats);
 /* diagnostics of the device-resident search of this space: out[0] searches run on the device, [1] buffer enlargements,
  * [2] pushes of a state already in OPEN in the last search (the reference's INCONS holds a state once per improvement),
- * [3..9] 10-ns ticks thread 0 of the workgroup spent, last search: select + pop, evaluation (GetSuccs loop body),
- * getOrCreateState, relaxation + pushes, epsilon steps (reorder), load / store of the launch state; [10] states on the
- * device, [11] heap entries cached in LDS; [12..15] 0 */
+ * [3..9] 10-ns ticks the search wave of the workgroup spent, last search: (idle), select + pop, until the waypoint lanes'
+ * round has closed (ancestor prefetch, preparing the next round, waiting), getOrCreateState, relaxation + pushes, epsilon
+ * steps (reorder), load / store of the launch state; [10] states on the device, [11] heap entries cached in LDS;
+ * [12] evaluation rounds opened on a guess of the next pop, [13] guesses the pop confirmed; [14..15] 0 */
 int smplx_search_counters(const smplx_space* s, int64_t out[16]);
 /* nq independent queries (each its own smplx_space: goal, BFS grid, state table) on one GPU.  Device-resident search
  * (default): one workgroup per query, all in ONE launch when the queries share grid, robot and primitives.  Host-driven
