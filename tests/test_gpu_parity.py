@@ -96,6 +96,35 @@ def test_state_validity_with_deeper_sphere_trees(small_cfg):
     _compare_expand(o, s, Q[ok.astype(bool)][:40])
 
 
+def test_bfs_grid_from_goal_cells_at_brick_corners(small_cfg):
+    """The BFS records keep, for every 8x8x8 brick, copies of the eight cells diagonally across its corners, written by the
+    bricks that own them: goals ON such corner cells (the seed writes the copy) and next to them, whole grid against the
+    oracle's."""
+    from oracle_binding import Oracle
+    from smpl_amd import capi
+    o = Oracle(small_cfg)
+    s = capi.Space.from_config(small_cfg)
+    o.set_goal_joint(small_cfg.goal, small_cfg.goal_tol)
+    walls = o.bfs_grid().reshape(-1)
+    n = small_cfg.grid.dims
+    org, res = np.array(small_cfg.grid.origin), small_cfg.grid.res
+    dx, dy = n[0] + 2, n[1] + 2
+    done = 0
+    for base in ((8, 8, 8), (16, 24, 8), (24, 16, 16), (32, 32, 24), (40, 8, 32)):
+        for d in ((-1, -1, -1), (0, 0, 0), (-1, 0, -1), (0, -1, 0)):
+            c = tuple(b + e for b, e in zip(base, d))
+            if not all(0 <= c[a] < n[a] for a in range(3)):
+                continue
+            if walls[(c[2] + 1) * dx * dy + (c[1] + 1) * dx + (c[0] + 1)] == 0x7FFFFFFF:
+                continue       # a wall cell there in this scene
+            xyz = list(org + res * (np.array(c) + 0.5))
+            o.set_goal_xyz(xyz, small_cfg.goal_tol)
+            s.set_goal_xyz(xyz, small_cfg.goal_tol)
+            assert np.array_equal(o.bfs_grid(), s.bfs_grid()), f"goal cell {c}"
+            done += 1
+    assert done >= 8
+
+
 def test_sphere_positions_bitwise(ctx):
     cfg, o, s = ctx
     Q = _random_states(64, 1)
